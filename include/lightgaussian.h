@@ -1,0 +1,158 @@
+/*
+ * lightgaussian.h -- C ABI of the MI355X-native LightGaussian rasterizer (liblightgaussian_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of VITA-Group/LightGaussian: the differentiable
+ * tile rasterizer + per-Gaussian Global-Significance accumulation + its backward.  In the
+ * reference that path lives in the un-vendored CUDA extension
+ *     submodules/compress-diff-gaussian-rasterization            (/root/reference/.gitmodules:6-8)
+ * and is reached only through
+ *     gaussian_renderer/__init__.py:14-17   (import of GaussianRasterizationSettings / GaussianRasterizer)
+ *     gaussian_renderer/__init__.py:52-68   (settings record, 13 fields)
+ *     gaussian_renderer/__init__.py:106-115 (render call, returns color, radii)
+ *     gaussian_renderer/__init__.py:209-218 (count call, returns count, score, color, radii)
+ * The published extension exposes three torch-typed entry points behind that Python API
+ * (rasterize_gaussians / count_gaussians / rasterize_gaussians_backward).  The entry points below
+ * are what a binding of that path binds instead: plain device pointers, sizes and a stream --
+ * no torch types.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller, fp32 contiguous unless noted
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *   - functions return LG_OK or a negative error code; lg_last_error() gives the message
+ *   - the library keeps no state between calls (re-entrant per stream)
+ */
+#ifndef LIGHTGAUSSIAN_H
+#define LIGHTGAUSSIAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_ABI_VERSION 1
+
+enum {
+    LG_OK = 0,
+    LG_ERR_INVALID_ARGUMENT = -1, /* bad sizes / exclusive inputs violated (reference: Python Exception before launch) */
+    LG_ERR_DEVICE = -2,           /* HIP error (reference: std::runtime_error -> RuntimeError) */
+    LG_ERR_ALLOC = -3,            /* binning allocator callback returned NULL */
+    LG_ERR_PREFILTERED = -4       /* prefiltered=1 but a Gaussian failed the frustum test */
+};
+
+/* per-hit weight of the significance score; OPACITY is LightGaussian's GS_j = sum 1(hit) * sigma_j */
+enum { LG_WEIGHT_ONE = 0, LG_WEIGHT_OPACITY = 1, LG_WEIGHT_ALPHA = 2, LG_WEIGHT_ALPHA_T = 3 };
+
+/* flags */
+enum {
+    LG_FLAG_DEBUG = 1,     /* sync + check after every kernel (reference: raster_settings.debug, gaussian_renderer/__init__.py:64) */
+    LG_FLAG_FAST_EXP = 2,  /* hardware exp in the blend kernels: image/gradients within 1e-5, counts no longer bit-pinned */
+    LG_FLAG_PROFILE = 4    /* record per-kernel hipEvent timings, read back with lg_profile_read() */
+};
+
+/* GaussianRasterizationSettings (gaussian_renderer/__init__.py:52-66), minus f_count which selects the entry point */
+typedef struct lg_view {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float* bg;         /* [3] */
+    float scale_modifier;
+    const float* viewmatrix; /* [4,4] world_view_transform (row-vector convention, scene/cameras.py:70-72) */
+    const float* projmatrix; /* [4,4] full_proj_transform (scene/cameras.py:80-84) */
+    int32_t sh_degree;       /* active degree D; the coefficient count M is in lg_gaussians */
+    const float* campos;     /* [3] */
+    int32_t prefiltered;
+    uint32_t flags;          /* LG_FLAG_* */
+} lg_view;
+
+/* the 8 tensor kwargs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:106-115); means2D is gradient-only */
+typedef struct lg_gaussians {
+    int32_t N;                   /* number of Gaussians */
+    int32_t M;                   /* SH coefficients per channel in `shs` (1,4,9,16); 0 when colors_precomp is used */
+    const float* means3D;        /* [N,3] */
+    const float* shs;            /* [N,M,3] or NULL */
+    const float* colors_precomp; /* [N,3]   or NULL   (exactly one of shs / colors_precomp) */
+    const float* opacities;      /* [N,1] */
+    const float* scales;         /* [N,3]   or NULL */
+    const float* rotations;      /* [N,4]   or NULL   (r,x,y,z) */
+    const float* cov3D_precomp;  /* [N,6]   or NULL   (exactly one of scales+rotations / cov3D_precomp) */
+} lg_gaussians;
+
+/* Scratch sizing.  geom: per-Gaussian projected state; img: per-pixel state; binning: (tile,Gaussian)
+ * instance lists for `num_rendered` instances; backward scratch: per-Gaussian gradient accumulators. */
+size_t lg_geom_bytes(int32_t N);
+size_t lg_img_bytes(int32_t width, int32_t height);
+size_t lg_binning_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t lg_backward_scratch_bytes(int32_t N);
+
+/* Called once per forward, after the instance count is known, to obtain the binning buffer
+ * (same role as the resize-callbacks of the published extension). Must return a device pointer
+ * valid on `stream` with at least `bytes` bytes, or NULL. */
+typedef void* (*lg_alloc_fn)(void* user, size_t bytes);
+
+/*
+ * Forward render  (replaces rasterize_gaussians; Python call site gaussian_renderer/__init__.py:106-115).
+ *   out_color [3,H,W]   out_radii [N] int32 (>0 <=> rasterised)
+ *   geom / img: caller scratch of lg_geom_bytes / lg_img_bytes (kept for backward)
+ *   *binning_out / *num_rendered: the buffer returned by `alloc` and the instance count (kept for backward)
+ * One blocking device->host read of the instance count happens inside (as in the reference extension).
+ */
+int lg_forward(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+               float* out_color, int32_t* out_radii, void** binning_out, int64_t* num_rendered, void* stream);
+
+/*
+ * Forward render + Global Significance accumulation  (replaces count_gaussians; call site
+ * gaussian_renderer/__init__.py:209-218 with f_count=True).
+ *   out_count [N] int32: number of pixels each Gaussian contributed to
+ *   out_score [N] fp32 : per-view significance; for ONE/OPACITY weights it is bit-identical to
+ *                        out_count[j] sequential float additions of the weight (what per-hit
+ *                        atomicAdd produces), computed from the exact integer count.
+ */
+int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+                     int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
+                     void** binning_out, int64_t* num_rendered, void* stream);
+
+/*
+ * Backward  (replaces rasterize_gaussians_backward).  dL_dcolor [3,H,W] -> dense gradients, zero for
+ * Gaussians that were not rasterised.  Output pointers may be NULL when the matching input was NULL.
+ *   dL_dmeans2D [N,3] (NDC units, z = 0; consumed by scene/gaussian_model.py:784-788)
+ *   dL_dmeans3D [N,3]  dL_dshs [N,M,3]  dL_dcolors [N,3]  dL_dopacity [N,1]
+ *   dL_dscales [N,3]   dL_drotations [N,4]  dL_dcov3D [N,6]
+ *   scratch: lg_backward_scratch_bytes(N)
+ */
+int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii, const void* geom, const void* binning,
+                const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                float* dL_dcov3D, void* scratch, void* stream);
+
+/* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
+ * prune pass to rebuild per-view scores from integer counts. */
+int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream);
+
+/* --- introspection / measurement ------------------------------------------------------------ */
+int lg_abi_version(void);
+const char* lg_last_error(void);
+
+/* Per-kernel timings recorded when LG_FLAG_PROFILE is set (hipEvents on the launch stream).
+ * lg_profile_read synchronises the stream-recorded events, then fills up to `cap` entries. */
+typedef struct lg_kernel_time {
+    char name[32];
+    double total_ms;
+    int64_t launches;
+} lg_kernel_time;
+int lg_profile_read(lg_kernel_time* out, int cap);
+void lg_profile_reset(void);
+
+/* statistics of the most recent forward on this thread (for bench roofline accounting) */
+typedef struct lg_stats {
+    int64_t num_rendered;  /* instances after exact footprint culling */
+    int64_t num_visible;   /* Gaussians with radii > 0 */
+} lg_stats;
+int lg_last_stats(lg_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTGAUSSIAN_H */

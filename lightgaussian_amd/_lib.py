@@ -1,0 +1,122 @@
+"""ctypes binding of the C ABI declared in include/lightgaussian.h.
+
+PyTorch is used only for device memory and streams; every compute call goes through
+liblightgaussian_hip.so.  There is NO fallback: if the library is missing or a GPU call
+fails, this module raises -- it never routes to a CPU/PyTorch implementation.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblightgaussian_hip.so")
+
+LG_OK = 0
+LG_ERR_INVALID_ARGUMENT = -1
+LG_ERR_DEVICE = -2
+LG_ERR_ALLOC = -3
+LG_ERR_PREFILTERED = -4
+
+WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
+FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE = 1, 2, 4
+
+EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
+           "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
+           "lg_profile_read", "lg_profile_reset", "lg_last_stats"]
+
+
+class lg_view(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("bg", C.c_void_p), ("scale_modifier", C.c_float), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("sh_degree", C.c_int32), ("campos", C.c_void_p),
+                ("prefiltered", C.c_int32), ("flags", C.c_uint32)]
+
+
+class lg_gaussians(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
+class lg_kernel_time(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+class lg_stats(C.Structure):
+    _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int64)]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src_dir] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL, stderr=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the native library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X rasterizer has no CPU/PyTorch fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    vp, P = C.c_void_p, C.POINTER
+    lib.lg_geom_bytes.restype = C.c_size_t; lib.lg_geom_bytes.argtypes = [C.c_int32]
+    lib.lg_img_bytes.restype = C.c_size_t; lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.lg_binning_bytes.restype = C.c_size_t; lib.lg_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.lg_backward_scratch_bytes.restype = C.c_size_t; lib.lg_backward_scratch_bytes.argtypes = [C.c_int32]
+    lib.lg_forward.restype = C.c_int
+    lib.lg_forward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, ALLOC_FN, vp, vp, vp, P(vp), P(C.c_int64), vp]
+    lib.lg_forward_count.restype = C.c_int
+    lib.lg_forward_count.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, ALLOC_FN, vp, C.c_int32, vp, vp, vp, vp, P(vp),
+                                     P(C.c_int64), vp]
+    lib.lg_backward.restype = C.c_int
+    lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 8 + [vp, vp]
+    lib.lg_score_from_count.restype = C.c_int
+    lib.lg_score_from_count.argtypes = [C.c_int32, vp, vp, vp, vp]
+    lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
+    lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []
+    lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
+    lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []
+    lib.lg_last_stats.restype = C.c_int; lib.lg_last_stats.argtypes = [P(lg_stats)]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map C error codes onto the reference's Python-side behaviour: invalid argument combos ->
+    Exception, device errors -> RuntimeError."""
+    if rc == LG_OK:
+        return
+    msg = load().lg_last_error().decode("utf-8", "replace")
+    if rc == LG_ERR_INVALID_ARGUMENT:
+        raise Exception(msg)
+    raise RuntimeError(f"lightgaussian_hip error {rc}: {msg}")
+
+
+def profile_read():
+    """Per-kernel hipEvent totals recorded under FLAG_PROFILE: {name: (total_ms, launches)}."""
+    lib = load()
+    arr = (lg_kernel_time * 32)()
+    n = lib.lg_profile_read(arr, 32)
+    return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(min(n, 32))}
+
+
+def profile_reset():
+    load().lg_profile_reset()
+
+
+def last_stats():
+    s = lg_stats()
+    load().lg_last_stats(C.byref(s))
+    return {"num_rendered": s.num_rendered, "num_visible": s.num_visible}

@@ -1,0 +1,834 @@
+// lg_kernels.hip -- gfx950 (CDNA4, wave64) kernels + C ABI of the LightGaussian rasterizer.
+//
+// Pipeline (one view):
+//   K1 lg_preprocess      per Gaussian : project, EWA splat, SH->RGB, exact footprint culling, tile count
+//   K2 inclusive scan     (rocPRIM)    : instance offsets, R = total instances
+//   K3 lg_duplicate       per Gaussian : (tile<<32 | depth bits, id) for every tile of the tight rectangle
+//   K4 radix sort         (rocPRIM)    : stable, by (tile, depth); ties keep Gaussian-id order
+//   K5 lg_tile_ranges     per instance : [start,end) of every tile
+//   K6 lg_blend_fwd       per tile     : 4 autonomous waves (8x8 pixels each); each wave compacts the
+//                                        Gaussians overlapping ITS 8x8 block into an LDS queue and blends
+//                                        front-to-back; wave-ballot early termination; count variant
+//                                        does one int atomic per (wave, Gaussian) from a popcount
+//   K7 lg_blend_bwd       per tile     : same traversal back-to-front; the 9 per-pair partials are
+//                                        reduced across the wave with DPP adds, one atomic set per wave
+//   K8+K9 lg_preprocess_bwd per Gaussian: conic/mean2D/colour grads -> means3D, SH, scale, rotation
+//
+// Written for wave64 / 256-thread workgroups; no CUDA compatibility paths.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lightgaussian.h"
+#include "lg_math.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static thread_local lg_stats g_stats = {0, 0};
+
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return fail(LG_ERR_DEVICE, #expr, _e);      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel event timing (LG_FLAG_PROFILE)
+struct ProfEntry { std::string name; double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+static thread_local std::vector<ProfEntry> g_prof;
+
+static ProfEntry& prof_entry(const char* name)
+{
+    for (auto& p : g_prof) if (p.name == name) return p;
+    g_prof.emplace_back();
+    g_prof.back().name = name;
+    return g_prof.back();
+}
+struct ProfScope {
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t s; const char* name; bool on;
+    ProfScope(bool on_, const char* n, hipStream_t st) : s(st), name(n), on(on_)
+    {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) { hipEventRecord(b, s); prof_entry(name).pending.emplace_back(a, b); }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// scratch carving (all sub-buffers 256-byte aligned)
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct GeomView {
+    float4* rec;        // [N][3]  {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
+    float* depth;       // [N]
+    float* cov3D;       // [N][6]
+    uint32_t* clamp;    // [N]
+    uint2* trect;       // [N] tight tile rectangle: x = tx0 | ty0<<16, y = tx1 | ty1<<16
+    uint32_t* touched;  // [N]
+    uint32_t* offsets;  // [N] inclusive scan of touched
+    uint32_t* counters; // [16]: 0 = visible count, 1 = prefiltered violation
+    void* scan_temp; size_t scan_temp_bytes;
+    size_t total;
+};
+
+static size_t scan_temp_bytes_for(int N)
+{
+    size_t bytes = 0;
+    hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N);
+    return bytes;
+}
+
+static GeomView carve_geom(void* base, int N)
+{
+    GeomView g;
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    size_t n = (size_t)(N > 0 ? N : 1);
+    g.rec = (float4*)take(n * 48);
+    g.depth = (float*)take(n * 4);
+    g.cov3D = (float*)take(n * 24);
+    g.clamp = (uint32_t*)take(n * 4);
+    g.trect = (uint2*)take(n * 8);
+    g.touched = (uint32_t*)take(n * 4);
+    g.offsets = (uint32_t*)take(n * 4);
+    g.counters = (uint32_t*)take(64);
+    g.scan_temp_bytes = scan_temp_bytes_for((int)n);
+    g.scan_temp = take(g.scan_temp_bytes);
+    g.total = off;
+    return g;
+}
+
+struct ImgView { float* final_T; uint32_t* n_contrib; size_t total; };
+static ImgView carve_img(void* base, int W, int H)
+{
+    ImgView v; size_t off = 0; char* p = (char*)base; size_t P = (size_t)W * H;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    v.final_T = (float*)take(P * 4);
+    v.n_contrib = (uint32_t*)take(P * 4);
+    v.total = off;
+    return v;
+}
+
+struct BinView {
+    uint64_t *keys_in, *keys_out; uint32_t *vals_in, *vals_out; uint2* ranges;
+    void* sort_temp; size_t sort_temp_bytes; size_t total;
+};
+static int key_bits_for(int ntiles)
+{
+    int b = 0;
+    while ((1 << b) < ntiles) b++;
+    return 32 + b;
+}
+static BinView carve_bin(void* base, int64_t R, int W, int H)
+{
+    BinView v; size_t off = 0; char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    size_t n = (size_t)(R > 0 ? R : 1);
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
+    v.keys_in = (uint64_t*)take(n * 8);
+    v.keys_out = (uint64_t*)take(n * 8);
+    v.vals_in = (uint32_t*)take(n * 4);
+    v.vals_out = (uint32_t*)take(n * 4);
+    v.ranges = (uint2*)take((size_t)gx * gy * 8);
+    size_t tb = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (int)n, 0, key_bits_for(gx * gy));
+    v.sort_temp_bytes = tb;
+    v.sort_temp = take(tb);
+    v.total = off;
+    return v;
+}
+
+extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
+extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
+extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H) { return carve_bin(nullptr, R, W, H).total; }
+extern "C" size_t lg_backward_scratch_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * 12 * sizeof(float)); }
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t prefix_popc(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// DPP wave reduction: after the call lane 63 holds the sum over all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0x111, 0xf>(v); // row_shr:1
+    v = dpp_add<0x112, 0xf>(v); // row_shr:2
+    v = dpp_add<0x114, 0xf>(v); // row_shr:4
+    v = dpp_add<0x118, 0xf>(v); // row_shr:8   -> lane 15 of every row holds the row total
+    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: preprocess
+struct ViewConsts { float vm[16]; float pm[16]; float campos[3]; };
+
+__global__ void __launch_bounds__(256)
+lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
+              const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+              const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+              const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+              const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float vm[16], pm[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
+    cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+    bool vis = false;
+    if (i < N) {
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        uint32_t touched = 0;
+        int radius = 0;
+        // near-plane test first so culled Gaussians cost 12 bytes of reads
+        const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+        if (vz > 0.2f) {
+            float cov[6];
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov[k] = cov3D_precomp[6 * (size_t)i + k];
+            } else {
+                float s[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+                const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+                float q[4] = { q4.x, q4.y, q4.z, q4.w };
+                lg_cov3d(s, mod, q, cov);
+            }
+            const float op = opacities[i];
+            LgSplat sp;
+            if (lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp)) {
+                vis = true;
+                radius = sp.radius;
+                touched = (uint32_t)((sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0));
+                float rgb[3];
+                uint32_t cb = 0;
+                if (colors_precomp) {
+                    rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
+                } else {
+                    // M <= 16 coefficients x 3 channels; rows are 12*M bytes, 16-byte aligned when M is a multiple of 4... load scalar-wise, L1 absorbs
+                    float sh[48];
+                    const float* src = shs + (size_t)i * M * 3;
+                    const int ncoef = (D + 1) * (D + 1);
+                    for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? src[k] : 0.0f;
+                    lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
+                }
+                g.rec[3 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
+                g.rec[3 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
+                g.rec[3 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
+                g.depth[i] = sp.depth;
+#pragma unroll
+                for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)i + k] = cov[k];
+                g.clamp[i] = cb;
+                g.trect[i] = make_uint2((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16));
+            }
+        } else if (prefiltered) {
+            g.counters[1] = 1u;
+        }
+        radii[i] = radius;
+        g.touched[i] = touched;
+    }
+    const uint64_t m = __ballot(vis);
+    if (lane_id() == 0 && m) atomicAdd(&g.counters[0], (uint32_t)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: duplicate with keys
+__global__ void __launch_bounds__(256)
+lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
+             const uint2* __restrict__ trect, const float* __restrict__ depth, uint64_t* __restrict__ keys,
+             uint32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t t = touched[i];
+    if (t == 0) return;
+    uint32_t off = offsets[i] - t;
+    const uint2 r = trect[i];
+    const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+    const uint64_t d = (uint64_t)__float_as_uint(depth[i]);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
+            vals[off] = (uint32_t)i;
+            off++;
+        }
+}
+
+// K5: tile ranges from sorted keys
+__global__ void __launch_bounds__(256)
+lg_tile_ranges(uint32_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
+    }
+    if (i == R - 1) ranges[t].y = R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile <-> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order); give every
+// XCD a contiguous band of tiles so that neighbouring tiles -- which share Gaussians -- hit the same L2.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles_pad8)
+{
+    const int per = ntiles_pad8 >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+#define LG_Q 64 // LDS queue depth per wave = one batch
+
+// K6 / K6c: forward blend
+template <bool COUNT, bool FSCORE, bool EXACT>
+__global__ void __launch_bounds__(256)
+lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
+             float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
+{
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
+    if (tile >= ntiles) return;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
+    const uint2 range = ranges[tile];
+
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = range.x; base < range.y; base += LG_Q) {
+        if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
+        const uint32_t idx = base + lane;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (idx < range.y) {
+            const uint32_t id = point_list[idx];
+            r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+            // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
+            hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
+        }
+        uint64_t mask = __ballot(hit);
+        if (mask == 0) continue;
+        if (hit) {
+            const uint32_t pos = prefix_popc(mask);
+            q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int mycnt = 0;
+        float myf = 0.0f;
+        uint32_t j = 0;
+        const uint32_t rel = base - range.x + 1; // contributor index of source lane 0
+        while (mask) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
+            int res = 0;
+            float alpha = 0.0f, Tprev = T;
+            if (!done) {
+                res = lg_blend_pair<EXACT>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, pxf, pyf, T, C0, C1, C2, alpha);
+                if (res == 2) done = true;
+                if (res == 1) last = rel + src;
+            }
+            if (COUNT) {
+                const uint64_t cm = __ballot(res == 1);
+                if (lane == j) mycnt = (int)__popcll(cm);
+                if (FSCORE) {
+                    float wv = (res == 1) ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
+                    wv = wave_sum_to_lane63(wv);
+                    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
+                    if (lane == j) myf = tot;
+                }
+            }
+            j++;
+        }
+        if (COUNT) {
+            // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
+            if (lane < j && mycnt > 0) {
+                const uint32_t id = __float_as_uint(q2[wave][lane].w);
+                atomicAdd(&count[id], mycnt);
+                if (FSCORE) atomicAdd(&fscore[id], myf);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = fmaf(T, bg[0], C0);
+        out_color[HW + pid] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+    }
+}
+
+// per-view score from the exact integer count (ONE / OPACITY weights)
+__global__ void __launch_bounds__(256)
+lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = count[i];
+    score[i] = c > 0 ? lg_seqsum32(weight ? weight[i] : 1.0f, (uint32_t)c) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: backward blend.  acc: [N][12] floats (9 used): dmean2D px x,y | dA dB dC | dopacity | drgb
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
+             const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+             float* __restrict__ acc)
+{
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
+    if (tile >= ntiles) return;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
+    const uint2 range = ranges[tile];
+    const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+
+    const float T_final = inside ? final_T[pid] : 0.0f;
+    float T = T_final;
+    const uint32_t last = inside ? n_contrib[pid] : 0u;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[HW + pid]; g2 = dL_dpix[2 * HW + pid]; }
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
+
+    // highest contributor index any pixel of this wave used: nothing behind it matters
+    uint32_t wmax = last;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, s));
+    if (wmax == 0) return;
+    const uint32_t n_list = range.y - range.x;
+    if (wmax > n_list) wmax = n_list;
+    // batches of 64 list positions, aligned like the forward pass: batch k covers rel (1-based) in [64k+1, 64k+64]
+    for (int k = (int)((wmax - 1) / LG_Q); k >= 0; k--) {
+        const uint32_t base = range.x + (uint32_t)k * LG_Q;
+        const uint32_t idx = base + lane;
+        const uint32_t relpos = (uint32_t)k * LG_Q + lane + 1;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (idx < range.y && relpos <= wmax) {
+            const uint32_t id = point_list[idx];
+            r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+            hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
+        }
+        uint64_t mask = __ballot(hit);
+        if (mask == 0) continue;
+        uint32_t n = (uint32_t)__popcll(mask);
+        if (hit) {
+            const uint32_t pos = prefix_popc(mask);
+            q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // back to front: highest set bit first
+        while (mask) {
+            const uint32_t src = 63u - (uint32_t)__builtin_clzll(mask);
+            mask &= ~(1ull << src);
+            n--;
+            const float4 a = q0[wave][n], b = q1[wave][n], c = q2[wave][n];
+            const uint32_t rel = (uint32_t)k * LG_Q + src + 1;
+            float p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0, p8 = 0;
+            bool contrib = false;
+            if (rel <= last) {
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+                if (power <= 0.0f) {
+                    const float G = EXACT ? lg_exp(power) : __expf(power);
+                    const float op = b.y;
+                    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+                    if (alpha >= LG_ALPHA_MIN) {
+                        contrib = true;
+                        const float A = -2.0f * a.z, B = -a.w, Cc = -2.0f * b.x;
+                        T = T / (1.0f - alpha);
+                        const float dch = alpha * T;
+                        const float c0 = b.z, c1 = b.w, c2 = c.x;
+                        a0 = last_alpha * lc0 + (1.0f - last_alpha) * a0;
+                        a1 = last_alpha * lc1 + (1.0f - last_alpha) * a1;
+                        a2 = last_alpha * lc2 + (1.0f - last_alpha) * a2;
+                        lc0 = c0; lc1 = c1; lc2 = c2;
+                        float dL_dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
+                        dL_dalpha = dL_dalpha * T;
+                        last_alpha = alpha;
+                        dL_dalpha = dL_dalpha + (-T_final / (1.0f - alpha)) * bg_dot;
+                        const float dL_dG = op * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        p0 = dL_dG * (-gdx * A - gdy * B);
+                        p1 = dL_dG * (-gdy * Cc - gdx * B);
+                        p2 = -0.5f * gdx * dx * dL_dG;
+                        p3 = -gdx * dy * dL_dG;
+                        p4 = -0.5f * gdy * dy * dL_dG;
+                        p5 = G * dL_dalpha;
+                        p6 = dch * g0; p7 = dch * g1; p8 = dch * g2;
+                    }
+                }
+            }
+            if (__ballot(contrib) == 0) continue;
+            p0 = wave_sum_to_lane63(p0); p1 = wave_sum_to_lane63(p1); p2 = wave_sum_to_lane63(p2);
+            p3 = wave_sum_to_lane63(p3); p4 = wave_sum_to_lane63(p4); p5 = wave_sum_to_lane63(p5);
+            p6 = wave_sum_to_lane63(p6); p7 = wave_sum_to_lane63(p7); p8 = wave_sum_to_lane63(p8);
+            if (lane == 63) {
+                float* dst = acc + (size_t)__float_as_uint(c.w) * 12;
+                atomicAdd(dst + 0, p0); atomicAdd(dst + 1, p1); atomicAdd(dst + 2, p2);
+                atomicAdd(dst + 3, p3); atomicAdd(dst + 4, p4); atomicAdd(dst + 5, p5);
+                atomicAdd(dst + 6, p6); atomicAdd(dst + 7, p7); atomicAdd(dst + 8, p8);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 + K9 fused: per-Gaussian backward
+__global__ void __launch_bounds__(256)
+lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
+                  const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+                  const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                  const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                  const int32_t* __restrict__ radii, const float* __restrict__ cov3D, const uint32_t* __restrict__ clamp,
+                  const float* __restrict__ acc, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D,
+                  float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                  float* __restrict__ dL_dscales, float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float vm[16], pm[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
+    cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+    const bool vis = radii[i] > 0;
+    float m2[3] = {0, 0, 0}, m3[3] = {0, 0, 0}, dop = 0.0f, dsc[3] = {0, 0, 0}, drot[4] = {0, 0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
+    float dcol[3] = {0, 0, 0};
+    float* dsh_row = dL_dshs ? dL_dshs + (size_t)i * M * 3 : nullptr;
+    if (vis) {
+        float a[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = acc[(size_t)i * 12 + k];
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        float S[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) S[k] = cov3D[6 * (size_t)i + k];
+        LgGradOut go;
+        lg_backward_geom(vm, pm, px, py, pz, S, a, W, H, tanfovx, tanfovy, go);
+        m2[0] = go.mean2D[0]; m2[1] = go.mean2D[1];
+        m3[0] = go.mean3D[0]; m3[1] = go.mean3D[1]; m3[2] = go.mean3D[2];
+        dop = a[5];
+        if (colors_precomp) {
+            dcol[0] = a[6]; dcol[1] = a[7]; dcol[2] = a[8];
+        } else if (shs) {
+            const uint32_t cb = clamp[i];
+            float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
+            float sh[48];
+            const float* src = shs + (size_t)i * M * 3;
+            const int ncoef = (D + 1) * (D + 1);
+            for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? src[k] : 0.0f;
+            // zero the coefficients above the active degree, then let the store callback fill the live ones
+            for (int k = ncoef * 3; k < M * 3; k++) dsh_row[k] = 0.0f;
+            lg_backward_sh(D, sh, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh_row[k * 3 + c] = v; });
+        }
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov[k] = go.cov3D[k];
+        } else {
+            float s[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+            const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+            float q[4] = { q4.x, q4.y, q4.z, q4.w };
+            lg_backward_cov3d(s, mod, q, go.cov3D, dsc, drot);
+        }
+    } else if (dsh_row) {
+        for (int k = 0; k < M * 3; k++) dsh_row[k] = 0.0f;
+    }
+    dL_dmeans2D[3 * (size_t)i] = m2[0]; dL_dmeans2D[3 * (size_t)i + 1] = m2[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
+    dL_dmeans3D[3 * (size_t)i] = m3[0]; dL_dmeans3D[3 * (size_t)i + 1] = m3[1]; dL_dmeans3D[3 * (size_t)i + 2] = m3[2];
+    dL_dopacity[i] = dop;
+    if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = dcol[0]; dL_dcolors[3 * (size_t)i + 1] = dcol[1]; dL_dcolors[3 * (size_t)i + 2] = dcol[2]; }
+    if (dL_dscales) { dL_dscales[3 * (size_t)i] = dsc[0]; dL_dscales[3 * (size_t)i + 1] = dsc[1]; dL_dscales[3 * (size_t)i + 2] = dsc[2]; }
+    if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static int check_args(const lg_view* v, const lg_gaussians* g)
+{
+    if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
+    if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
+    if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
+        return fail(LG_ERR_INVALID_ARGUMENT, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool sr = g->scales != nullptr && g->rotations != nullptr;
+    if ((g->scales != nullptr) != (g->rotations != nullptr) || sr == (g->cov3D_precomp != nullptr))
+        return fail(LG_ERR_INVALID_ARGUMENT, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (g->shs) {
+        if (!(g->M == 1 || g->M == 4 || g->M == 9 || g->M == 16)) return fail(LG_ERR_INVALID_ARGUMENT, "M must be 1, 4, 9 or 16");
+        if (v->sh_degree < 0 || v->sh_degree > 3 || (v->sh_degree + 1) * (v->sh_degree + 1) > g->M)
+            return fail(LG_ERR_INVALID_ARGUMENT, "sh_degree needs (D+1)^2 <= M, D <= 3");
+    }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos || !g->means3D || !g->opacities)
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing required pointer");
+    const int gx = (v->image_width + LG_TILE - 1) / LG_TILE, gy = (v->image_height + LG_TILE - 1) / LG_TILE;
+    if (gx >= 65536 || gy >= 65536) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    return LG_OK;
+}
+
+#define KCHECK(name)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) return fail(LG_ERR_DEVICE, name " launch", _e);                \
+        if (debug) {                                                                         \
+            _e = hipStreamSynchronize(stream);                                               \
+            if (_e != hipSuccess) return fail(LG_ERR_DEVICE, name " execution", _e);         \
+        }                                                                                    \
+    } while (0)
+
+static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, void* img_p, lg_alloc_fn alloc, void* alloc_user,
+                        int weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
+                        void** binning_out, int64_t* num_rendered, void* stream_p)
+{
+    int rc = check_args(v, g);
+    if (rc != LG_OK) return rc;
+    if (!geom_p || !img_p || !out_color || !out_radii || !alloc) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    const bool count = out_count != nullptr;
+    if (count && !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count needs score");
+    if (count && (weight_policy < 0 || weight_policy > 3)) return fail(LG_ERR_INVALID_ARGUMENT, "bad weight policy");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
+    const int N = g->N, W = v->image_width, H = v->image_height;
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
+    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    GeomView geo = carve_geom(geom_p, N);
+    ImgView img = carve_img(img_p, W, H);
+    const size_t HW = (size_t)W * H;
+
+    if (binning_out) *binning_out = nullptr;
+    if (num_rendered) *num_rendered = 0;
+    uint32_t h_counters[2] = {0, 0}, h_R = 0;
+    if (N > 0) {
+        HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
+        {
+            ProfScope ps(prof, "preprocess", stream);
+            lg_preprocess<<<(N + 255) / 256, 256, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
+                                                                v->prefiltered, v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs,
+                                                                g->colors_precomp, g->opacities, g->scales, g->rotations,
+                                                                g->cov3D_precomp, geo, out_radii);
+        }
+        KCHECK("lg_preprocess");
+        {
+            ProfScope ps(prof, "scan", stream);
+            size_t tb = geo.scan_temp_bytes;
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(geo.scan_temp, tb, geo.touched, geo.offsets, N, stream));
+        }
+        HIP_TRY(hipMemcpyAsync(&h_R, geo.offsets + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_counters, geo.counters, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
+    const int64_t R = h_R;
+    g_stats.num_rendered = R;
+    g_stats.num_visible = h_counters[0];
+    if (num_rendered) *num_rendered = R;
+
+    void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H).total);
+    if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
+    if (binning_out) *binning_out = bin_p;
+    BinView bin = carve_bin(bin_p, R, W, H);
+    HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
+    const uint32_t* point_list = bin.vals_out;
+    if (R > 0) {
+        {
+            ProfScope ps(prof, "duplicate", stream);
+            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.trect, geo.depth, bin.keys_in, bin.vals_in);
+        }
+        KCHECK("lg_duplicate");
+        {
+            ProfScope ps(prof, "sort", stream);
+            size_t tb = bin.sort_temp_bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.vals_in, bin.vals_out, (int)R, 0,
+                                                       key_bits_for(ntiles), stream));
+        }
+        {
+            ProfScope ps(prof, "tile_ranges", stream);
+            lg_tile_ranges<<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, bin.keys_out, bin.ranges);
+        }
+        KCHECK("lg_tile_ranges");
+    }
+    if (count) {
+        HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
+        HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
+    }
+    {
+        ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
+        dim3 grid(ntiles_pad8), block(256);
+#define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, point_list, geo.rec, v->bg,     \
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
+        const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
+        if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
+        else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
+        else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
+#undef LAUNCH_FWD
+    }
+    KCHECK("lg_blend_fwd");
+    (void)HW;
+    if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
+        ProfScope ps(prof, "score", stream);
+        lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
+        KCHECK("lg_score_kernel");
+    }
+    return LG_OK;
+}
+
+extern "C" int lg_forward(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+                          float* out_color, int32_t* out_radii, void** binning_out, int64_t* num_rendered, void* stream)
+{
+    return forward_impl(view, g, geom, img, alloc, alloc_user, LG_WEIGHT_OPACITY, out_color, out_radii, nullptr, nullptr, binning_out,
+                        num_rendered, stream);
+}
+
+extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+                                int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
+                                void** binning_out, int64_t* num_rendered, void* stream)
+{
+    if (!out_count || !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count/score outputs required");
+    return forward_impl(view, g, geom, img, alloc, alloc_user, weight_policy, out_color, out_radii, out_count, out_score, binning_out,
+                        num_rendered, stream);
+}
+
+extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
+                           const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                           float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                           float* dL_dcov3D, void* scratch, void* stream_p)
+{
+    int rc = check_args(v, g);
+    if (rc != LG_OK) return rc;
+    if (!radii || !geom_p || !bin_p || !img_p || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacity || !scratch)
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    if ((g->shs && !dL_dshs) || (g->colors_precomp && !dL_dcolors) || (g->scales && (!dL_dscales || !dL_drotations)) ||
+        (g->cov3D_precomp && !dL_dcov3D))
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for a provided input");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
+    const int N = g->N, W = v->image_width, H = v->image_height;
+    if (N == 0) return LG_OK;
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
+    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
+    ImgView img = carve_img(const_cast<void*>(img_p), W, H);
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H);
+    float* acc = (float*)scratch;
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)N * 12 * sizeof(float), stream));
+    if (R > 0) {
+        ProfScope ps(prof, "blend_bwd", stream);
+        if (fast)
+            lg_blend_bwd<false><<<ntiles_pad8, 256, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+                                                                 img.final_T, img.n_contrib, dL_dcolor, acc);
+        else
+            lg_blend_bwd<true><<<ntiles_pad8, 256, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+                                                                img.final_T, img.n_contrib, dL_dcolor, acc);
+    }
+    KCHECK("lg_blend_bwd");
+    {
+        ProfScope ps(prof, "preprocess_bwd", stream);
+        lg_preprocess_bwd<<<(N + 255) / 256, 256, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
+                                                                v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs, g->colors_precomp,
+                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.cov3D, geo.clamp, acc,
+                                                                dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales,
+                                                                dL_drotations, dL_dcov3D);
+    }
+    KCHECK("lg_preprocess_bwd");
+    return LG_OK;
+}
+
+extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream_p)
+{
+    if (N < 0 || (N > 0 && (!count || !score))) return fail(LG_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (N == 0) return LG_OK;
+    hipStream_t stream = (hipStream_t)stream_p;
+    lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_score_kernel launch", e);
+    return LG_OK;
+}
+
+extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
+extern "C" const char* lg_last_error(void) { return g_err.c_str(); }
+extern "C" int lg_last_stats(lg_stats* out)
+{
+    if (!out) return LG_ERR_INVALID_ARGUMENT;
+    *out = g_stats;
+    return LG_OK;
+}
+
+extern "C" void lg_profile_reset(void)
+{
+    for (auto& p : g_prof)
+        for (auto& ev : p.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    g_prof.clear();
+}
+
+extern "C" int lg_profile_read(lg_kernel_time* out, int cap)
+{
+    int n = 0;
+    for (auto& p : g_prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0.0f;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                p.ms += ms; p.n += 1;
+            }
+            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+        }
+        p.pending.clear();
+        if (out && n < cap) {
+            memset(&out[n], 0, sizeof(lg_kernel_time));
+            strncpy(out[n].name, p.name.c_str(), sizeof(out[n].name) - 1);
+            out[n].total_ms = p.ms; out[n].launches = p.n;
+        }
+        n++;
+    }
+    return n;
+}

@@ -1,0 +1,96 @@
+"""Host-side mirror of the reference's render boundary (gaussian_renderer/__init__.py).
+
+render()        <- gaussian_renderer/__init__.py:22-124
+count_render()  <- gaussian_renderer/__init__.py:127-229
+Same names, argument meaning, result-dict keys and error behaviour; the only change is the import
+target of the rasterizer (our HIP library instead of the CUDA submodule) and that tensors are
+created on the Gaussians' own device instead of the hard-coded "cuda" (identical on one GPU,
+required for one-process-per-GPU sharding).
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .sh_utils import eval_sh
+
+
+def _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, f_count):
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx,
+        tanfovy=tanfovy,
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        debug=pipe.debug,
+        f_count=f_count,
+    )
+
+
+def _inputs(viewpoint_camera, pc, pipe, scaling_modifier, override_color):
+    means3D = pc.get_xyz
+    opacity = pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    return means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp
+
+
+def _screenspace_points(pc):
+    # zero tensor whose .grad receives the 2D (NDC) mean gradients, gaussian_renderer/__init__.py:37-46
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    return screenspace_points
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False))
+    means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp = _inputs(
+        viewpoint_camera, pc, pipe, scaling_modifier, override_color)
+    rendered_image, radii = rasterizer(
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}
+
+
+def count_render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    """render() + per-Gaussian hit count and Global Significance score (f_count=True)."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, True))
+    means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp = _inputs(
+        viewpoint_camera, pc, pipe, scaling_modifier, override_color)
+    gaussians_count, important_score, rendered_image, radii = rasterizer(
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "gaussians_count": gaussians_count, "important_score": important_score}

@@ -1,0 +1,224 @@
+"""Drop-in for the `diff_gaussian_rasterization` module of the reference.
+
+Mirrors the Python surface the reference binds to at
+  gaussian_renderer/__init__.py:14-17   import GaussianRasterizationSettings, GaussianRasterizer
+  gaussian_renderer/__init__.py:52-66   13-field settings record (incl. LightGaussian's f_count)
+  gaussian_renderer/__init__.py:106-115 rasterizer(means3D=..., means2D=..., shs=..., colors_precomp=...,
+                                                   opacities=..., scales=..., rotations=..., cov3D_precomp=...)
+                                        -> (color, radii)
+  gaussian_renderer/__init__.py:209-218 with f_count=True -> (gaussians_count, important_score, color, radii)
+and the stale variant gaussian_renderer/gaussian_count.py:69,112 (ctor kw f_count, .forward_counter()).
+
+All arithmetic runs in liblightgaussian_hip.so (hand-written gfx950 kernels) through the C ABI of
+include/lightgaussian.h; torch supplies device memory, the current stream and autograd plumbing.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    f_count: bool = False
+
+
+# process-wide knobs that are not part of the reference API
+_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": False, "profile": False}
+
+
+def set_option(name, value):
+    """weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
+    fast_exp: hardware exp in render() (count renders always use the bit-pinned exp);
+    profile: record per-kernel hipEvent timings (read with _lib.profile_read())."""
+    if name not in _OPTIONS:
+        raise KeyError(name)
+    _OPTIONS[name] = value
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(t, dev):
+    """contiguous fp32 tensor on dev, or None for None / empty placeholders."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+    return t
+
+
+class _Call:
+    """Holds the tensors referenced by the C structs alive for the duration of a call."""
+
+    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact):
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("lightgaussian_amd rasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
+        self.dev = dev
+        self.means3D = _prep(means3D, dev)
+        self.sh = _prep(sh, dev)
+        self.colors = _prep(colors_precomp, dev)
+        self.opac = _prep(opacities, dev)
+        self.scales = _prep(scales, dev)
+        self.rots = _prep(rotations, dev)
+        self.cov = _prep(cov3D_precomp, dev)
+        self.bg = _prep(rs.bg, dev)
+        self.vm = _prep(rs.viewmatrix, dev)
+        self.pm = _prep(rs.projmatrix, dev)
+        self.cp = _prep(rs.campos, dev)
+        N = self.means3D.shape[0] if self.means3D is not None else 0
+        M = 0 if self.sh is None else int(self.sh.shape[1])
+        flags = 0
+        if rs.debug:
+            flags |= _lib.FLAG_DEBUG
+        if _OPTIONS["fast_exp"] and not exact:
+            flags |= _lib.FLAG_FAST_EXP
+        if _OPTIONS["profile"]:
+            flags |= _lib.FLAG_PROFILE
+        self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                                 _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
+                                 int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags)
+        self.g = _lib.lg_gaussians(N, M, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
+                                   _ptr(self.scales), _ptr(self.rots), _ptr(self.cov))
+        self.N, self.M = N, M
+
+
+def _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    # same messages/semantics as the published rasterizer's forward()
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+       ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        lib = _lib.load()
+        rs = raster_settings
+        count = bool(rs.f_count)
+        call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count)
+        dev, N = call.dev, call.N
+        H, W = int(rs.image_height), int(rs.image_width)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            geom = torch.empty(lib.lg_geom_bytes(N), **u8)
+            img = torch.empty(lib.lg_img_bytes(W, H), **u8)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((N,), dtype=torch.int32, device=dev)
+            holder = {}
+
+            def _alloc(_user, nbytes):
+                holder["t"] = torch.empty(max(int(nbytes), 1), **u8)
+                return holder["t"].data_ptr()
+
+            cb = _lib.ALLOC_FN(_alloc)
+            bin_ptr = C.c_void_p()
+            R = C.c_int64(0)
+            if count:
+                gcount = torch.empty((N,), dtype=torch.int32, device=dev)
+                score = torch.empty((N,), dtype=torch.float32, device=dev)
+                rc = lib.lg_forward_count(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None,
+                                          int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount),
+                                          _ptr(score), C.byref(bin_ptr), C.byref(R), stream)
+            else:
+                rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color),
+                                    _ptr(radii), C.byref(bin_ptr), C.byref(R), stream)
+            _lib.check(rc)
+        binning = holder.get("t")
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(R.value)
+        ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
+                   scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
+        ctx.save_for_backward(call.means3D, call.sh, call.colors, call.opac, call.scales, call.rots, call.cov, radii,
+                              geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        if count:
+            ctx.mark_non_differentiable(gcount, score)
+            return gcount, score, color, radii
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        rs = ctx.raster_settings
+        grad_color = grads[2] if rs.f_count else grads[0]
+        means3D, sh, colors, opac, scales, rots, cov, radii, geom, binning, img = ctx.saved_tensors
+        call = _Call(rs, means3D, sh, colors, opac, scales, rots, cov, exact=bool(rs.f_count))
+        dev, N, M = call.dev, call.N, call.M
+        H, W = int(rs.image_height), int(rs.image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if grad_color is None:
+            grad_color = torch.zeros((3, H, W), **f32)
+        grad_color = _prep(grad_color, dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            g_means2D = torch.empty((N, 3), **f32)
+            g_means3D = torch.empty((N, 3), **f32)
+            g_opac = torch.empty((N, 1), **f32)
+            g_sh = torch.empty((N, M, 3), **f32) if call.sh is not None else None
+            g_col = torch.empty((N, 3), **f32) if call.colors is not None else None
+            g_sc = torch.empty((N, 3), **f32) if call.scales is not None else None
+            g_rot = torch.empty((N, 4), **f32) if call.rots is not None else None
+            g_cov = torch.empty((N, 6), **f32) if call.cov is not None else None
+            scratch = torch.empty(lib.lg_backward_scratch_bytes(N), dtype=torch.uint8, device=dev)
+            rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                 C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
+                                 _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov),
+                                 _ptr(scratch), stream)
+            _lib.check(rc)
+        had_sh, had_col, had_sc, had_cov = ctx.had
+        return (g_means3D, g_means2D, g_sh if had_sh else None, g_col if had_col else None, g_opac,
+                g_sc if had_sc else None, g_rot if had_sc else None, g_cov if had_cov else None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings, f_count=None):
+        super().__init__()
+        if f_count is not None:  # stale ctor form, gaussian_renderer/gaussian_count.py:69
+            raster_settings = raster_settings._replace(f_count=bool(f_count))
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test only (never called by the reference; kept for API completeness)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            ph = torch.cat([positions, torch.ones_like(positions[:, :1])], dim=1)
+            return (ph @ rs.viewmatrix.to(positions.device))[:, 2] > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
+
+    def forward_counter(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                        cov3D_precomp=None):
+        """Stale count entry point (gaussian_renderer/gaussian_count.py:112)."""
+        _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        rs = self.raster_settings._replace(f_count=True)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

@@ -1,0 +1,135 @@
+// CPU harness around the PRODUCT's device-math header (lightgaussian_amd/csrc/lg_math.h).
+// Test infrastructure: compiled with g++ (-ffp-contract=off) so the not-gpu tests can pin the
+// canonical arithmetic, the seqsum32 binade stepping and the exact footprint culling against the
+// oracle bit for bit, without a GPU.  It emulates the kernels' traversal semantics (tight tile
+// rectangles, per-8x8-block box test, front-to-back blend) with plain loops.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../lightgaussian_amd/csrc/lg_math.h"
+
+extern "C" {
+
+float h_exp(float x) { return lg_exp(x); }
+float h_seqsum32(float w, uint32_t c) { return lg_seqsum32(w, c); }
+
+struct HSplat { LgSplat s; float op, rgb[3], cov[6]; uint32_t clamp; int vis; };
+
+// Full forward emulation.  cull=1: tight rectangles + per-wave box test (what the kernels do);
+// cull=0: reference rectangles, no box test.
+int h_forward(int N, int M, int D, int W, int H, const float* bg, const float* means3D, const float* shs,
+              const float* colors_precomp, const float* opacities, const float* scales, float mod,
+              const float* rotations, const float* cov3D_precomp, const float* vm, const float* pm,
+              const float* campos, float tanfovx, float tanfovy, int cull, float* out_color, int* radii, int* count,
+              float* score, float* xy, float* conic_opacity, float* rgb_out, int* ref_rect, int* tight_rect,
+              long long* num_instances)
+{
+    std::vector<HSplat> sp(N);
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    for (int i = 0; i < N; i++) {
+        HSplat& h = sp[i];
+        h.vis = 0; radii[i] = 0;
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+        if (!(vz > 0.2f)) continue;
+        if (cov3D_precomp) memcpy(h.cov, cov3D_precomp + 6 * i, 24);
+        else lg_cov3d(scales + 3 * i, mod, rotations + 4 * i, h.cov);
+        h.op = opacities[i];
+        if (!lg_project(vm, pm, px, py, pz, h.cov, h.op, W, H, tanfovx, tanfovy, h.s)) continue;
+        h.vis = 1; radii[i] = h.s.radius;
+        if (colors_precomp) { for (int c = 0; c < 3; c++) h.rgb[c] = colors_precomp[3 * i + c]; h.clamp = 0; }
+        else {
+            float sh[48];
+            const int ncoef = (D + 1) * (D + 1);
+            for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? shs[(size_t)i * M * 3 + k] : 0.0f;
+            lg_sh_to_rgb(D, sh, px, py, pz, campos, h.rgb, h.clamp);
+        }
+        xy[2 * i] = h.s.x; xy[2 * i + 1] = h.s.y;
+        conic_opacity[4 * i] = -2.0f * h.s.ha; conic_opacity[4 * i + 1] = -h.s.nb; conic_opacity[4 * i + 2] = -2.0f * h.s.hc;
+        conic_opacity[4 * i + 3] = h.op;
+        for (int c = 0; c < 3; c++) rgb_out[3 * i + c] = h.rgb[c];
+        ref_rect[4 * i] = h.s.rx0; ref_rect[4 * i + 1] = h.s.ry0; ref_rect[4 * i + 2] = h.s.rx1; ref_rect[4 * i + 3] = h.s.ry1;
+        tight_rect[4 * i] = h.s.tx0; tight_rect[4 * i + 1] = h.s.ty0; tight_rect[4 * i + 2] = h.s.tx1; tight_rect[4 * i + 3] = h.s.ty1;
+    }
+    struct Inst { uint64_t key; uint32_t id; };
+    std::vector<Inst> inst;
+    for (int i = 0; i < N; i++) {
+        if (!sp[i].vis) continue;
+        const LgSplat& s = sp[i].s;
+        int x0 = cull ? s.tx0 : s.rx0, x1 = cull ? s.tx1 : s.rx1, y0 = cull ? s.ty0 : s.ry0, y1 = cull ? s.ty1 : s.ry1;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++)
+                inst.push_back({((uint64_t)(y * gx + x) << 32) | lg_f2bits(s.depth), (uint32_t)i});
+    }
+    std::stable_sort(inst.begin(), inst.end(), [](const Inst& a, const Inst& b) { return a.key < b.key; });
+    *num_instances = (long long)inst.size();
+    std::vector<uint32_t> lo(gx * gy, 0), hi(gx * gy, 0);
+    for (size_t k = 0; k < inst.size(); k++) {
+        uint32_t t = (uint32_t)(inst[k].key >> 32);
+        if (k == 0 || t != (uint32_t)(inst[k - 1].key >> 32)) lo[t] = (uint32_t)k;
+        hi[t] = (uint32_t)k + 1;
+    }
+    if (count) memset(count, 0, sizeof(int) * N);
+    for (int t = 0; t < gx * gy; t++) {
+        const int tx = t % gx, ty = t / gx;
+        for (int wave = 0; wave < 4; wave++) {
+            const int wx0 = tx * 16 + (wave & 1) * 8, wy0 = ty * 16 + (wave >> 1) * 8;
+            const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
+            for (int lane = 0; lane < 64; lane++) {
+                const int pxi = wx0 + (lane & 7), pyi = wy0 + (lane >> 3);
+                if (pxi >= W || pyi >= H) continue;
+                float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, alpha;
+                for (uint32_t k = lo[t]; k < hi[t]; k++) {
+                    const HSplat& h = sp[inst[k].id];
+                    if (cull) {
+                        bool hit = (h.s.x + h.s.hx >= bx0) && (h.s.x - h.s.hx <= bx1) && (h.s.y + h.s.hy >= by0) && (h.s.y - h.s.hy <= by1);
+                        if (!hit) continue;
+                    }
+                    int res = lg_blend_pair<true>(h.s.x, h.s.y, h.s.ha, h.s.nb, h.s.hc, h.op, h.rgb[0], h.rgb[1], h.rgb[2],
+                                                  (float)pxi, (float)pyi, T, C0, C1, C2, alpha);
+                    if (res == 2) break;
+                    if (res == 1 && count) count[inst[k].id]++;
+                }
+                const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+                out_color[pid] = fmaf(T, bg[0], C0);
+                out_color[HW + pid] = fmaf(T, bg[1], C1);
+                out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+            }
+        }
+    }
+    if (score && count)
+        for (int i = 0; i < N; i++) score[i] = count[i] > 0 ? lg_seqsum32(opacities[i], (uint32_t)count[i]) : 0.0f;
+    return 0;
+}
+
+// Per-Gaussian backward stage given the 9 blend sums (acc [N][9]).
+void h_backward_geom(int N, int M, int D, int W, int H, const float* means3D, const float* shs, const float* scales, float mod,
+                     const float* rotations, const float* cov3D, const unsigned char* clamped, const int* radii,
+                     const float* vm, const float* pm, const float* campos, float tanfovx, float tanfovy, const float* acc,
+                     float* dmeans2D, float* dmeans3D, float* dshs, float* dscales, float* drots, float* dcov)
+{
+    for (int i = 0; i < N; i++) {
+        for (int k = 0; k < 3; k++) { dmeans2D[3 * i + k] = 0; dmeans3D[3 * i + k] = 0; dscales[3 * i + k] = 0; }
+        for (int k = 0; k < 4; k++) drots[4 * i + k] = 0;
+        for (int k = 0; k < 6; k++) dcov[6 * i + k] = 0;
+        for (int k = 0; k < 3 * M; k++) dshs[(size_t)i * 3 * M + k] = 0;
+        if (!(radii[i] > 0)) continue;
+        LgGradOut go;
+        lg_backward_geom(vm, pm, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], cov3D + 6 * i, acc + 9 * i, W, H, tanfovx, tanfovy, go);
+        float m3[3] = { go.mean3D[0], go.mean3D[1], go.mean3D[2] };
+        float dRGB[3];
+        for (int c = 0; c < 3; c++) dRGB[c] = clamped[3 * i + c] ? 0.0f : acc[9 * i + 6 + c];
+        float sh[48];
+        const int ncoef = (D + 1) * (D + 1);
+        for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? shs[(size_t)i * M * 3 + k] : 0.0f;
+        float* row = dshs + (size_t)i * 3 * M;
+        lg_backward_sh(D, sh, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], campos, dRGB, m3,
+                       [&](int k, int c, float v) { row[k * 3 + c] = v; });
+        lg_backward_cov3d(scales + 3 * i, mod, rotations + 4 * i, go.cov3D, dscales + 3 * i, drots + 4 * i);
+        for (int k = 0; k < 6; k++) dcov[6 * i + k] = go.cov3D[k];
+        dmeans2D[3 * i] = go.mean2D[0]; dmeans2D[3 * i + 1] = go.mean2D[1];
+        for (int k = 0; k < 3; k++) dmeans3D[3 * i + k] = m3[k];
+    }
+}
+}
