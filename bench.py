@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- views/sec of the LightGaussian differentiable-render hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[2], the one the 200 views/s target is quoted on): 3M synthetic
+Gaussians (SURVEY.md section 8d generator, seed 20250103), 1920x1080, SH degree 3.  One STEP = one
+view through the reference's own boundary: gaussian_renderer.render() (getters + rasterizer
+forward) -> L1 loss vs a ground-truth image -> backward to the raw GaussianModel parameters
+(rasterizer backward + getter backward).  No optimizer step: it is not part of the path.
+`--mode fwd` times render() only, `--mode count` times count_render() (+ the sharded
+significance reduction when N > 1).
+
+Multi-GPU: one process per GPU, Gaussians replicated, cameras sharded (rank r renders views
+r, r+N, ...): weak scaling, no data-path collective in fwd/fwdbwd; `count` ends with the RCCL
+count all-reduce + ordered score exchange of lightgaussian_amd.prune.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel, algorithmic bytes / measured (hipEvent) launch time vs 8 TB/s
+  cpu_baseline -- the CPU oracle (oracle/, a port; the reference has no CPU render path) on the
+                  host cores, bounded sample, rank 0 at N=1 only
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured-copy ceiling is 6290
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count"], default="fwdbwd")
+    ap.add_argument("--n-gaussians", type=int, default=3_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--views", type=int, default=200, help="cameras on the orbit; steps cycle through them")
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-n", type=int, default=0, help="Gaussians in the CPU sample (0 = same as workload)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, V, R, P, M):
+    """SURVEY.md section 8d per-view algorithmic HBM bytes, split per kernel."""
+    return {
+        "preprocess": 16 * N + (76 + 12 * M + 28) * V,
+        "scan": 8 * N,
+        "duplicate": 12 * R,
+        "sort": 24 * R,
+        "tile_ranges": 8 * R,
+        "blend_fwd": 40 * R + 20 * P,
+        "blend_fwd_count": 40 * R + 20 * P + 8 * N,
+        "score": 12 * N,
+        "blend_bwd": 76 * R + 20 * P,
+        "preprocess_bwd": (108 + 12 * M) * V + (92 + 12 * M) * N,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lightgaussian_amd import _lib, synthetic as syn
+    from lightgaussian_amd import rasterizer
+    from lightgaussian_amd.gaussian_renderer import render, count_render
+    from lightgaussian_amd.prune import prune_list_sharded
+
+    _lib.load()
+    rasterizer.set_option("fast_exp", not args.exact_exp)
+    N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2
+    g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree)
+    pc = g_cpu.to(dev)
+    pipe = syn.PipelineParams()
+    bg = torch.zeros(3, device=dev)  # black, prune_finetune.py:87-88
+    my_views = list(range(rank, args.views, world)) or [0]
+    cams = {k: syn.orbit_camera(k, args.views, W, H).to(dev) for k in my_views}
+
+    # ground truth for the L1 loss: render of a perturbed copy (sigma = 0.01 on every raw parameter)
+    gts = {}
+    if args.mode == "fwdbwd":
+        gen = torch.Generator("cpu").manual_seed(syn.SEED + 1)
+        pert = syn.SyntheticGaussians(*[t + 0.01 * torch.randn(t.shape, generator=gen) for t in
+                                        (g_cpu._xyz, g_cpu._features_dc, g_cpu._features_rest, g_cpu._scaling,
+                                         g_cpu._rotation, g_cpu._opacity)], args.sh_degree, args.sh_degree).to(dev)
+        with torch.no_grad():
+            for k in my_views[: max(1, min(len(my_views), args.steps + args.warmup))]:
+                gts[k] = render(cams[k], pert, pipe, bg)["render"].clone()
+        del pert
+    pc.requires_grad_(args.mode == "fwdbwd")
+    params = [pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity]
+
+    def step(i):
+        k = my_views[i % len(my_views)]
+        if args.mode == "fwdbwd":
+            if k not in gts:
+                k = next(iter(gts))
+            for p in params:
+                p.grad = None
+            pkg = render(cams[k], pc, pipe, bg)
+            loss = (pkg["render"] - gts[k]).abs().mean()
+            loss.backward()
+        elif args.mode == "fwd":
+            with torch.no_grad():
+                render(cams[k], pc, pipe, bg)
+        else:
+            with torch.no_grad():
+                count_render(cams[k], pc, pipe, bg)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if args.mode == "count" and world > 1:
+        pass  # the per-view loop above is the sharded body; the reduction is timed below
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed  # whole-job views/s: every rank did `steps` views
+
+    extra = {}
+    if args.mode == "count" and world > 1:
+        # the collective of the sharded prune pass (config C4), timed separately: counts all-reduce + ordered score exchange
+        class _Cams:
+            def __init__(self, c): self.c = c
+            def getTrainCameras(self): return self.c
+        sub = [syn.orbit_camera(k, args.views, W, H).to(dev) for k in range(min(args.views, 2 * world))]
+        barrier(); t1 = time.perf_counter()
+        with torch.no_grad():
+            prune_list_sharded(pc, _Cams(sub), pipe, bg)
+        barrier()
+        extra["sharded_prune_pass_s_for_%d_views" % len(sub)] = time.perf_counter() - t1
+
+    result = None
+    if rank == 0:
+        stats = _lib.last_stats()
+        with torch.no_grad():
+            vis = int((render(cams[my_views[0]], pc, pipe, bg)["radii"] > 0).sum().item())
+        stats = _lib.last_stats()
+        R, P = int(stats["num_rendered"]), W * H
+        result = {
+            "metric": "views/sec fwd+bwd @1080p (N Gaussians)" if args.mode == "fwdbwd" else f"views/sec {args.mode} @1080p (N Gaussians)",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N} synthetic Gaussians (SURVEY 8d generator, seed {syn.SEED}), {W}x{H}, SH degree {args.sh_degree}, "
+                                   f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
+                       "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
+                       "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
+                       "parallelism": f"camera-shard x{world}"},
+        }
+        result.update(extra)
+
+    # ---- roofline leg: per-kernel hipEvent timings of the same step (separate, untimed pass) ----
+    if rank == 0 and not args.no_roofline:
+        rasterizer.set_option("profile", True)
+        _lib.profile_reset()
+        nprof = max(3, min(10, args.steps))
+        for i in range(nprof):
+            step(i)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        rasterizer.set_option("profile", False)
+        _lib.profile_reset()
+        ab = algorithmic_bytes(N, vis, R, P, M)
+        per_kernel = {name: {"avg_ms": tot / max(n, 1), "launches_per_step": n / nprof} for name, (tot, n) in prof.items()}
+        dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches_per_step"])
+        avg_s = per_kernel[dom]["avg_ms"] * 1e-3
+        achieved = ab.get(dom, 0) / avg_s / 1e9 if avg_s > 0 else 0.0
+        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                              "algorithmic_bytes_per_launch": ab.get(dom, 0), "avg_launch_ms": round(per_kernel[dom]["avg_ms"], 4)}
+        result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
+        tot_bytes = sum(ab[k] * per_kernel[k]["launches_per_step"] for k in per_kernel if k in ab)
+        result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
+
+    # ---- cpu_baseline leg: the oracle on the host cores, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, g_cpu, W, H)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, g_cpu, W, H):
+    """Time the CPU oracle (a port: the reference has no CPU render path) on ONE view of
+    the same workload; the sample shrinks to 1M Gaussians when the full one would take too long."""
+    import numpy as np
+    from lightgaussian_amd import synthetic as syn
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    n = args.cpu_baseline_n or g_cpu.num
+    cam = syn.orbit_camera(0, args.views, W, H)
+    with torch.no_grad():
+        kw = dict(means3D=g_cpu.get_xyz[:n].numpy(), opacities=g_cpu.get_opacity[:n].numpy(), W=W, H=H,
+                  tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=np.zeros(3, np.float32),
+                  viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+                  campos=cam.camera_center.numpy(), sh_degree=args.sh_degree, shs=g_cpu.get_features[:n].numpy(),
+                  scales=g_cpu.get_scaling[:n].numpy(), rotations=g_cpu.get_rotation[:n].numpy())
+    t0 = time.perf_counter()
+    f = oracle.forward(count=(args.mode == "count"), **kw)
+    t_f = time.perf_counter() - t0
+    t_b = 0.0
+    if args.mode == "fwdbwd":
+        gimg = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
+        t0 = time.perf_counter()
+        oracle.backward(f, gimg)
+        t_b = time.perf_counter() - t0
+    return {"value": round(1.0 / (t_f + t_b), 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"1 view, {n} Gaussians, {W}x{H}, {args.mode} (oracle/lg_oracle.c, OpenMP, fp32; fwd {t_f:.2f}s bwd {t_b:.2f}s; "
+                      "rasterizer only, no getters/loss)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -47,7 +47,9 @@ enum { LG_WEIGHT_ONE = 0, LG_WEIGHT_OPACITY = 1, LG_WEIGHT_ALPHA = 2, LG_WEIGHT_
 /* flags */
 enum {
     LG_FLAG_DEBUG = 1,     /* sync + check after every kernel (reference: raster_settings.debug, gaussian_renderer/__init__.py:64) */
-    LG_FLAG_FAST_EXP = 2,  /* hardware exp in the blend kernels: image/gradients within 1e-5, counts no longer bit-pinned */
+    LG_FLAG_FAST_EXP = 2,  /* hardware exp/rcp in the blend kernels (training renders): image/gradients agree with the
+                              canonical path to ~1e-6, far inside the 1e-4 contract; never used for count renders,
+                              whose integer outputs are bit-pinned */
     LG_FLAG_PROFILE = 4    /* record per-kernel hipEvent timings, read back with lg_profile_read() */
 };
 
@@ -130,6 +132,9 @@ int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii
 /* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
  * prune pass to rebuild per-view scores from integer counts. */
 int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream);
+
+/* diagnostics: the packed wave reduction used by the backward blend, on one wave: in [64][9] -> out [9] */
+int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream);
 
 /* --- introspection / measurement ------------------------------------------------------------ */
 int lg_abi_version(void);

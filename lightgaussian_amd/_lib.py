@@ -22,7 +22,7 @@ FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE = 1, 2, 4
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
-           "lg_profile_read", "lg_profile_reset", "lg_last_stats"]
+           "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9"]
 
 
 class lg_view(C.Structure):
@@ -84,6 +84,7 @@ def load():
     lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 8 + [vp, vp]
     lib.lg_score_from_count.restype = C.c_int
     lib.lg_score_from_count.argtypes = [C.c_int32, vp, vp, vp, vp]
+    lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]

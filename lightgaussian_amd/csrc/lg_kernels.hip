@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,9 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 // ------------------------------------------------------------------------------------------------
 // optional per-kernel event timing (LG_FLAG_PROFILE)
 struct ProfEntry { std::string name; double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
-static thread_local std::vector<ProfEntry> g_prof;
+// process-wide (autograd runs backward on its own thread), guarded by a mutex
+static std::vector<ProfEntry> g_prof;
+static std::mutex g_prof_mu;
 
 static ProfEntry& prof_entry(const char* name)
 {
@@ -61,11 +64,15 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr; hipStream_t s; const char* name; bool on;
     ProfScope(bool on_, const char* n, hipStream_t st) : s(st), name(n), on(on_)
     {
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~ProfScope()
     {
-        if (on) { hipEventRecord(b, s); prof_entry(name).pending.emplace_back(a, b); }
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            prof_entry(name).pending.emplace_back(a, b);
+        }
     }
 };
 
@@ -89,7 +96,7 @@ struct GeomView {
 static size_t scan_temp_bytes_for(int N)
 {
     size_t bytes = 0;
-    hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N);
     return bytes;
 }
 
@@ -147,7 +154,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H)
     v.vals_out = (uint32_t*)take(n * 4);
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
     size_t tb = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                        (uint32_t*)nullptr, (int)n, 0, key_bits_for(gx * gy));
     v.sort_temp_bytes = tb;
     v.sort_temp = take(tb);
@@ -407,118 +414,224 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7: backward blend.  acc: [N][12] floats (9 used): dmean2D px x,y | dA dB dC | dopacity | drgb
+// K7: backward blend.  One wave per 16x16 tile, FOUR pixels per lane (the four 8x8 sub-blocks), so a
+// (tile, Gaussian) instance is reduced across lanes once, not once per 8x8 block.  Per batch of 64 list
+// entries: lane l gathers entry l and computes its 4-bit sub-block overlap mask; the wave then walks the
+// batch back to front, evaluating an entry only on the sub-blocks it overlaps (scalar branches on the
+// mask).  The 9 partials are reduced with permlane32/16 swaps + row DPP adds (8 values packed into two
+// registers: ~20 instructions instead of 54), parked in LDS, and flushed once per batch with 64-wide
+// atomics (lane j owns entry j).  acc: [N][12] floats (9 used): dmean2D px x,y | dA dB dC | dopacity | drgb
+typedef unsigned lg_u2v __attribute__((ext_vector_type(2)));
+
+// combine two registers into one: lower 32 lanes = 32-lane partial sums of a, upper 32 lanes = of b
+__device__ __forceinline__ float fold32(float a, float b)
+{
+    lg_u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// rows (16 lanes) of the result: (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    lg_u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+// Sums p[0..8] over the wave and writes the 9 totals to dst[0..8] (LDS).  Which 16-lane row ends up
+// with which value is fixed by the two folds: rows of w0 = (p0, p2, p1, p3), rows of w1 = (p4, p6, p5, p7).
+__device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* dst, uint32_t lane)
+{
+    const float u0 = fold32(p[0], p[1]), u1 = fold32(p[2], p[3]), u2 = fold32(p[4], p[5]), u3 = fold32(p[6], p[7]);
+    float w0 = fold16(u0, u1), w1 = fold16(u2, u3);
+    w0 = row_sum_to_lane15(w0);
+    w1 = row_sum_to_lane15(w1);
+    const float w8 = wave_sum_to_lane63(p[8]);
+    if ((lane & 15u) == 15u) {
+        const uint32_t r = lane >> 4;
+        const uint32_t k = ((r & 1u) << 1) | (r >> 1); // row -> value index inside the group of four
+        dst[k] = w0;
+        dst[4 + k] = w1;
+    }
+    if (lane == 63u) dst[8] = w8;
+}
+
+// One (pixel, Gaussian) step of the back-to-front replay.  EXACT = canonical arithmetic (same sequence as
+// the oracle); otherwise hardware exp / rcp and contraction allowed (training path, 1e-4 contract).
 template <bool EXACT>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const float4& c, float pxf, float pyf, float& T, float T_final,
+                                         float g0, float g1, float g2, float bg_dot, float& a0, float& a1, float& a2, float& last_alpha,
+                                         float& lc0, float& lc1, float& lc2, float (&p)[9])
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    if (power > 0.0f) return false;
+    const float op = b.y;
+    if (EXACT) {
+        const float G = lg_exp(power);
+        const float alpha = fminf(LG_ALPHA_MAX, op * G);
+        if (alpha < LG_ALPHA_MIN) return false;
+        const float A = -2.0f * a.z, B = -a.w, Cc = -2.0f * b.x;
+        T = T / (1.0f - alpha);
+        const float dch = alpha * T;
+        const float c0 = b.z, c1 = b.w, c2 = c.x;
+        a0 = last_alpha * lc0 + (1.0f - last_alpha) * a0;
+        a1 = last_alpha * lc1 + (1.0f - last_alpha) * a1;
+        a2 = last_alpha * lc2 + (1.0f - last_alpha) * a2;
+        lc0 = c0; lc1 = c1; lc2 = c2;
+        float dL_dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
+        dL_dalpha = dL_dalpha * T;
+        last_alpha = alpha;
+        dL_dalpha = dL_dalpha + (-T_final / (1.0f - alpha)) * bg_dot;
+        const float dL_dG = op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        p[0] += dL_dG * (-gdx * A - gdy * B);
+        p[1] += dL_dG * (-gdy * Cc - gdx * B);
+        p[2] += -0.5f * gdx * dx * dL_dG;
+        p[3] += -gdx * dy * dL_dG;
+        p[4] += -0.5f * gdy * dy * dL_dG;
+        p[5] += G * dL_dalpha;
+        p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+        return true;
+    } else {
+#pragma clang fp contract(fast)
+        const float G = __expf(power);
+        const float alpha = fminf(LG_ALPHA_MAX, op * G);
+        if (alpha < LG_ALPHA_MIN) return false;
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        T = T * inv;
+        const float dch = alpha * T;
+        const float c0 = b.z, c1 = b.w, c2 = c.x;
+        const float om = 1.0f - last_alpha;
+        a0 = last_alpha * lc0 + om * a0;
+        a1 = last_alpha * lc1 + om * a1;
+        a2 = last_alpha * lc2 + om * a2;
+        lc0 = c0; lc1 = c1; lc2 = c2;
+        float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * T - (T_final * inv) * bg_dot;
+        last_alpha = alpha;
+        const float dL_dG = op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
+        p[0] += dL_dG * (2.0f * a.z * gdx + a.w * gdy);
+        p[1] += dL_dG * (2.0f * b.x * gdy + a.w * gdx);
+        const float hg = -0.5f * dL_dG;
+        p[2] += hg * gdx * dx;
+        p[3] += -dL_dG * gdx * dy;
+        p[4] += hg * gdy * dy;
+        p[5] += G * dL_dalpha;
+        p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+        return true;
+    }
+}
+
+template <bool EXACT>
+__global__ void __launch_bounds__(64)
 lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
              const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
              float* __restrict__ acc)
 {
-    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
+    __shared__ float stage[LG_Q * 9];
     const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
     if (tile >= ntiles) return;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
-    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
-    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
     const uint2 range = ranges[tile];
-    const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+    const size_t HW = (size_t)H * W;
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
 
-    const float T_final = inside ? final_T[pid] : 0.0f;
-    float T = T_final;
-    const uint32_t last = inside ? n_contrib[pid] : 0u;
-    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-    if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[HW + pid]; g2 = dL_dpix[2 * HW + pid]; }
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f;
-
-    // highest contributor index any pixel of this wave used: nothing behind it matters
-    uint32_t wmax = last;
+    float pxf[4], pyf[4], T[4], Tfin[4], g0[4], g1[4], g2[4], bgd[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
+    uint32_t last[4];
+    uint32_t wmax = 0;
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, s));
+    for (int s = 0; s < 4; s++) {
+        const int pxi = tx * LG_TILE + (s & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (s >> 1) * 8 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const size_t pid = (size_t)pyi * W + pxi;
+        pxf[s] = (float)pxi; pyf[s] = (float)pyi;
+        Tfin[s] = inside ? final_T[pid] : 0.0f;
+        T[s] = Tfin[s];
+        last[s] = inside ? n_contrib[pid] : 0u;
+        g0[s] = inside ? dL_dpix[pid] : 0.0f;
+        g1[s] = inside ? dL_dpix[HW + pid] : 0.0f;
+        g2[s] = inside ? dL_dpix[2 * HW + pid] : 0.0f;
+        bgd[s] = bgr * g0[s] + bgg * g1[s] + bgb * g2[s];
+        a0[s] = a1[s] = a2[s] = la[s] = lc0[s] = lc1[s] = lc2[s] = 0.0f;
+        wmax = max(wmax, last[s]);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
     if (wmax == 0) return;
     const uint32_t n_list = range.y - range.x;
     if (wmax > n_list) wmax = n_list;
-    // batches of 64 list positions, aligned like the forward pass: batch k covers rel (1-based) in [64k+1, 64k+64]
+    const float tbx = (float)(tx * LG_TILE), tby = (float)(ty * LG_TILE);
+
     for (int k = (int)((wmax - 1) / LG_Q); k >= 0; k--) {
         const uint32_t base = range.x + (uint32_t)k * LG_Q;
-        const uint32_t idx = base + lane;
-        const uint32_t relpos = (uint32_t)k * LG_Q + lane + 1;
-        bool hit = false;
-        float4 r0, r1, r2;
-        if (idx < range.y && relpos <= wmax) {
-            const uint32_t id = point_list[idx];
+        const uint32_t nb = min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q); // entries of this batch (uniform)
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        if (lane < nb) {
+            const uint32_t id = point_list[base + lane];
             r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
-            hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
-        }
-        uint64_t mask = __ballot(hit);
-        if (mask == 0) continue;
-        uint32_t n = (uint32_t)__popcll(mask);
-        if (hit) {
-            const uint32_t pos = prefix_popc(mask);
-            q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
+            uint32_t m = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
+                const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
+                m |= (hit ? 1u : 0u) << s;
+            }
+            q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
         }
         __builtin_amdgcn_wave_barrier();
-        // back to front: highest set bit first
-        while (mask) {
-            const uint32_t src = 63u - (uint32_t)__builtin_clzll(mask);
-            mask &= ~(1ull << src);
-            n--;
-            const float4 a = q0[wave][n], b = q1[wave][n], c = q2[wave][n];
-            const uint32_t rel = (uint32_t)k * LG_Q + src + 1;
-            float p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0, p8 = 0;
+        uint64_t hitmask = 0;
+        for (int j = (int)nb - 1; j >= 0; j--) {
+            const float4 c = q2[j];
+            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+            if (m == 0) continue;
+            const float4 a = q0[j], b = q1[j];
+            const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
+            float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             bool contrib = false;
-            if (rel <= last) {
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
-                if (power <= 0.0f) {
-                    const float G = EXACT ? lg_exp(power) : __expf(power);
-                    const float op = b.y;
-                    const float alpha = fminf(LG_ALPHA_MAX, op * G);
-                    if (alpha >= LG_ALPHA_MIN) {
-                        contrib = true;
-                        const float A = -2.0f * a.z, B = -a.w, Cc = -2.0f * b.x;
-                        T = T / (1.0f - alpha);
-                        const float dch = alpha * T;
-                        const float c0 = b.z, c1 = b.w, c2 = c.x;
-                        a0 = last_alpha * lc0 + (1.0f - last_alpha) * a0;
-                        a1 = last_alpha * lc1 + (1.0f - last_alpha) * a1;
-                        a2 = last_alpha * lc2 + (1.0f - last_alpha) * a2;
-                        lc0 = c0; lc1 = c1; lc2 = c2;
-                        float dL_dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
-                        dL_dalpha = dL_dalpha * T;
-                        last_alpha = alpha;
-                        dL_dalpha = dL_dalpha + (-T_final / (1.0f - alpha)) * bg_dot;
-                        const float dL_dG = op * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        p0 = dL_dG * (-gdx * A - gdy * B);
-                        p1 = dL_dG * (-gdy * Cc - gdx * B);
-                        p2 = -0.5f * gdx * dx * dL_dG;
-                        p3 = -gdx * dy * dL_dG;
-                        p4 = -0.5f * gdy * dy * dL_dG;
-                        p5 = G * dL_dalpha;
-                        p6 = dch * g0; p7 = dch * g1; p8 = dch * g2;
-                    }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if (m & (1u << s)) {
+                    if (rel <= last[s])
+                        contrib |= bwd_pair<EXACT>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
+                                                   la[s], lc0[s], lc1[s], lc2[s], p);
                 }
             }
             if (__ballot(contrib) == 0) continue;
-            p0 = wave_sum_to_lane63(p0); p1 = wave_sum_to_lane63(p1); p2 = wave_sum_to_lane63(p2);
-            p3 = wave_sum_to_lane63(p3); p4 = wave_sum_to_lane63(p4); p5 = wave_sum_to_lane63(p5);
-            p6 = wave_sum_to_lane63(p6); p7 = wave_sum_to_lane63(p7); p8 = wave_sum_to_lane63(p8);
-            if (lane == 63) {
-                float* dst = acc + (size_t)__float_as_uint(c.w) * 12;
-                atomicAdd(dst + 0, p0); atomicAdd(dst + 1, p1); atomicAdd(dst + 2, p2);
-                atomicAdd(dst + 3, p3); atomicAdd(dst + 4, p4); atomicAdd(dst + 5, p5);
-                atomicAdd(dst + 6, p6); atomicAdd(dst + 7, p7); atomicAdd(dst + 8, p8);
-            }
+            wave_reduce9_to_lds(p, stage + j * 9, lane);
+            hitmask |= 1ull << j;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((hitmask >> lane) & 1ull) {
+            float* dst = acc + (size_t)__float_as_uint(r2.w) * 12;
+            const float* src = stage + lane * 9;
+#pragma unroll
+            for (int c9 = 0; c9 < 9; c9++) atomicAdd(dst + c9, src[c9]);
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// diagnostics: wave_reduce9_to_lds on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
+__global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
+{
+    __shared__ float dst[9];
+    float p[9];
+    for (int c = 0; c < 9; c++) p[c] = in[threadIdx.x * 9 + c];
+    wave_reduce9_to_lds(p, dst, threadIdx.x);
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -632,7 +745,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 {
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
-    if (!geom_p || !img_p || !out_color || !out_radii || !alloc) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    if (!geom_p || !img_p || !out_color || (!out_radii && g->N > 0) || !alloc) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
     const bool count = out_count != nullptr;
     if (count && !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count needs score");
     if (count && (weight_policy < 0 || weight_policy > 3)) return fail(LG_ERR_INVALID_ARGUMENT, "bad weight policy");
@@ -697,7 +810,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_tile_ranges");
     }
-    if (count) {
+    if (count && N > 0) {
         HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
         HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
     }
@@ -734,7 +847,7 @@ extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void
                                 int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
                                 void** binning_out, int64_t* num_rendered, void* stream)
 {
-    if (!out_count || !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count/score outputs required");
+    if (g && g->N > 0 && (!out_count || !out_score)) return fail(LG_ERR_INVALID_ARGUMENT, "count/score outputs required");
     return forward_impl(view, g, geom, img, alloc, alloc_user, weight_policy, out_color, out_radii, out_count, out_score, binning_out,
                         num_rendered, stream);
 }
@@ -765,10 +878,10 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
-            lg_blend_bwd<false><<<ntiles_pad8, 256, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+            lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, acc);
         else
-            lg_blend_bwd<true><<<ntiles_pad8, 256, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+            lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
                                                                 img.final_T, img.n_contrib, dL_dcolor, acc);
     }
     KCHECK("lg_blend_bwd");
@@ -795,6 +908,14 @@ extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float*
     return LG_OK;
 }
 
+extern "C" int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream_p)
+{
+    lg_debug_reduce9_kernel<<<1, 64, 0, (hipStream_t)stream_p>>>(in_64x9, out_9);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_reduce9 launch", e);
+    return LG_OK;
+}
+
 extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 extern "C" const char* lg_last_error(void) { return g_err.c_str(); }
 extern "C" int lg_last_stats(lg_stats* out)
@@ -806,21 +927,23 @@ extern "C" int lg_last_stats(lg_stats* out)
 
 extern "C" void lg_profile_reset(void)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& p : g_prof)
-        for (auto& ev : p.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+        for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     g_prof.clear();
 }
 
 extern "C" int lg_profile_read(lg_kernel_time* out, int cap)
 {
     int n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& p : g_prof) {
         for (auto& ev : p.pending) {
             float ms = 0.0f;
             if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
                 p.ms += ms; p.n += 1;
             }
-            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
         }
         p.pending.clear();
         if (out && n < cap) {

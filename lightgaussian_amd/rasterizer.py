@@ -38,12 +38,13 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # process-wide knobs that are not part of the reference API
-_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": False, "profile": False}
+_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False}
 
 
 def set_option(name, value):
     """weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
-    fast_exp: hardware exp in render() (count renders always use the bit-pinned exp);
+    fast_exp (default True): hardware exp/rcp in render() -- training renders; set False for the canonical,
+              bit-pinned arithmetic.  count renders (f_count=True) ALWAYS use the canonical arithmetic;
     profile: record per-kernel hipEvent timings (read with _lib.profile_read())."""
     if name not in _OPTIONS:
         raise KeyError(name)
