@@ -153,7 +153,7 @@ void lg_profile_reset(void);
 /* statistics of the most recent forward on this thread (for bench roofline accounting) */
 typedef struct lg_stats {
     int64_t num_rendered;  /* instances after exact footprint culling */
-    int64_t num_visible;   /* Gaussians with radii > 0 */
+    int64_t num_visible;   /* -1: not tracked on the device (count radii > 0 instead) */
 } lg_stats;
 int lg_last_stats(lg_stats* out);
 

@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <string>
@@ -81,11 +82,9 @@ struct ProfScope {
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomView {
-    float4* rec;        // [N][3]  {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
-    float* depth;       // [N]
-    float* cov3D;       // [N][6]
-    uint32_t* clamp;    // [N]
-    uint2* trect;       // [N] tight tile rectangle: x = tx0 | ty0<<16, y = tx1 | ty1<<16
+    float4* rec;        // [N][3]  blend record {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
+    float4* aux;        // [N][2]  backward record {cov3D[0..3]} {cov3D[4], cov3D[5], clamp-bits, -}
+    uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
     uint32_t* touched;  // [N]
     uint32_t* offsets;  // [N] inclusive scan of touched
     uint32_t* counters; // [16]: 0 = visible count, 1 = prefiltered violation
@@ -108,10 +107,8 @@ static GeomView carve_geom(void* base, int N)
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     size_t n = (size_t)(N > 0 ? N : 1);
     g.rec = (float4*)take(n * 48);
-    g.depth = (float*)take(n * 4);
-    g.cov3D = (float*)take(n * 24);
-    g.clamp = (uint32_t*)take(n * 4);
-    g.trect = (uint2*)take(n * 8);
+    g.aux = (float4*)take(n * 32);
+    g.tinfo = (uint4*)take(n * 16);
     g.touched = (uint32_t*)take(n * 4);
     g.offsets = (uint32_t*)take(n * 4);
     g.counters = (uint32_t*)take(64);
@@ -194,91 +191,135 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: preprocess
-struct ViewConsts { float vm[16]; float pm[16]; float campos[3]; };
+// K1: preprocess.  One wave per workgroup, 64 consecutive Gaussians.  The SH rows of the wave (64 x 12M
+// bytes, contiguous in memory) are fetched with coalesced 16-byte loads into LDS -- skipping rows of
+// culled Gaussians -- instead of 48 strided dword loads per lane.
+#define LG_PP 64
+#define LG_SH_MAXF 48 // floats per SH row at M = 16
 
-__global__ void __launch_bounds__(256)
+// cooperative copy of the wave's SH rows into LDS (flat layout, row stride = rowf floats)
+__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int i0, int rows, int rowf, uint64_t need_mask,
+                                              float* lds, uint32_t lane)
+{
+    const float* src = shs + (size_t)i0 * rowf;
+    const int nfl = rows * rowf;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    if (vec_ok) {
+        const int nvec = nfl >> 2;
+        for (int q = (int)lane; q < nvec; q += LG_PP) {
+            const int f = q << 2;
+            // rows are skipped only when a float4 never straddles two rows
+            if ((rowf & 3) == 0 && !((need_mask >> (f / rowf)) & 1ull)) continue;
+            *reinterpret_cast<float4*>(lds + f) = *reinterpret_cast<const float4*>(src + f);
+        }
+        for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) lds[f] = src[f];
+    } else {
+        for (int f = (int)lane; f < nfl; f += LG_PP) lds[f] = src[f];
+    }
+}
+
+__global__ void __launch_bounds__(LG_PP)
 lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
               const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
               const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    const uint32_t lane = threadIdx.x;
+    const int i0 = blockIdx.x * LG_PP;
+    const int i = i0 + (int)lane;
     float vm[16], pm[16], cp[3];
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
     bool vis = false;
+    float px = 0, py = 0, pz = 0, op = 0;
+    float cov[6] = {0, 0, 0, 0, 0, 0};
+    LgSplat sp;
     if (i < N) {
-        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-        uint32_t touched = 0;
-        int radius = 0;
+        px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2];
         // near-plane test first so culled Gaussians cost 12 bytes of reads
         const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
         if (vz > 0.2f) {
-            float cov[6];
             if (cov3D_precomp) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) cov[k] = cov3D_precomp[6 * (size_t)i + k];
             } else {
-                float s[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+                float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
                 const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
                 float q[4] = { q4.x, q4.y, q4.z, q4.w };
-                lg_cov3d(s, mod, q, cov);
+                lg_cov3d(sc, mod, q, cov);
             }
-            const float op = opacities[i];
-            LgSplat sp;
-            if (lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp)) {
-                vis = true;
-                radius = sp.radius;
-                touched = (uint32_t)((sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0));
-                float rgb[3];
-                uint32_t cb = 0;
-                if (colors_precomp) {
-                    rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
-                } else {
-                    // M <= 16 coefficients x 3 channels; rows are 12*M bytes, 16-byte aligned when M is a multiple of 4... load scalar-wise, L1 absorbs
-                    float sh[48];
-                    const float* src = shs + (size_t)i * M * 3;
-                    const int ncoef = (D + 1) * (D + 1);
-                    for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? src[k] : 0.0f;
-                    lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
-                }
-                g.rec[3 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
-                g.rec[3 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
-                g.rec[3 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
-                g.depth[i] = sp.depth;
-#pragma unroll
-                for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)i + k] = cov[k];
-                g.clamp[i] = cb;
-                g.trect[i] = make_uint2((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16));
-            }
+            op = opacities[i];
+            vis = lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp);
         } else if (prefiltered) {
             g.counters[1] = 1u;
+        }
+    }
+    const uint64_t vmask = __ballot(vis);
+    const int rowf = 3 * M;
+    if (shs && vmask) {
+        stage_sh_rows(shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (i < N) {
+        uint32_t touched = 0;
+        int radius = 0;
+        if (vis) {
+            radius = sp.radius;
+            touched = (uint32_t)((sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0));
+            float rgb[3];
+            uint32_t cb = 0;
+            if (colors_precomp) {
+                rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
+            } else {
+                float sh[LG_SH_MAXF];
+                const float* row = sh_rows + lane * rowf;
+                const int nact = (D + 1) * (D + 1) * 3;
+                if ((rowf & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < LG_SH_MAXF / 4; q++) {
+                        float4 v4 = make_float4(0, 0, 0, 0);
+                        if (q * 4 < nact) v4 = reinterpret_cast<const float4*>(row)[q];
+                        sh[4 * q] = v4.x; sh[4 * q + 1] = v4.y; sh[4 * q + 2] = v4.z; sh[4 * q + 3] = v4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
+                }
+                lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
+            }
+            g.rec[3 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
+            g.rec[3 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
+            g.rec[3 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
+            g.aux[2 * (size_t)i + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
+            g.aux[2 * (size_t)i + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
+            g.tinfo[i] = make_uint4((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16),
+                                    __float_as_uint(sp.depth), 0u);
         }
         radii[i] = radius;
         g.touched[i] = touched;
     }
-    const uint64_t m = __ballot(vis);
-    if (lane_id() == 0 && m) atomicAdd(&g.counters[0], (uint32_t)__popcll(m));
+    // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: duplicate with keys
 __global__ void __launch_bounds__(256)
 lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             const uint2* __restrict__ trect, const float* __restrict__ depth, uint64_t* __restrict__ keys,
-             uint32_t* __restrict__ vals)
+             const uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const uint32_t t = touched[i];
     if (t == 0) return;
     uint32_t off = offsets[i] - t;
-    const uint2 r = trect[i];
+    const uint4 r = tinfo[i];
     const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
-    const uint64_t d = (uint64_t)__float_as_uint(depth[i]);
+    const uint64_t d = (uint64_t)r.z;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
@@ -498,38 +539,51 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
         p[5] += G * dL_dalpha;
         p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
         return true;
-    } else {
-#pragma clang fp contract(fast)
-        const float G = __expf(power);
-        const float alpha = fminf(LG_ALPHA_MAX, op * G);
-        if (alpha < LG_ALPHA_MIN) return false;
-        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
-        T = T * inv;
-        const float dch = alpha * T;
-        const float c0 = b.z, c1 = b.w, c2 = c.x;
-        const float om = 1.0f - last_alpha;
-        a0 = last_alpha * lc0 + om * a0;
-        a1 = last_alpha * lc1 + om * a1;
-        a2 = last_alpha * lc2 + om * a2;
-        lc0 = c0; lc1 = c1; lc2 = c2;
-        float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * T - (T_final * inv) * bg_dot;
-        last_alpha = alpha;
-        const float dL_dG = op * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
-        p[0] += dL_dG * (2.0f * a.z * gdx + a.w * gdy);
-        p[1] += dL_dG * (2.0f * b.x * gdy + a.w * gdx);
-        const float hg = -0.5f * dL_dG;
-        p[2] += hg * gdx * dx;
-        p[3] += -dL_dG * gdx * dy;
-        p[4] += hg * gdy * dy;
-        p[5] += G * dL_dalpha;
-        p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
-        return true;
     }
+    return false;
 }
 
-template <bool EXACT>
+// Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
+// the whole sequence and invalid lanes are neutralised by zeroing dL/dalpha and the colour weight and by
+// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.)
+__device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
+                                              float& T, float T_final, float g0, float g1, float g2, float bg_dot, float& a0, float& a1,
+                                              float& a2, float (&p)[9])
+{
+#pragma clang fp contract(fast)
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
+    const float G = __expf(fminf(power, 0.0f));
+    const float op = b.y;
+    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    const float Tn = T * inv;
+    const float c0 = b.z, c1 = b.w, c2 = c.x;
+    // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence)
+    float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * Tn - (T_final * inv) * bg_dot;
+    dL_dalpha = ok ? dL_dalpha : 0.0f;
+    const float dch = ok ? alpha * Tn : 0.0f;
+    const float om = 1.0f - alpha;
+    T = ok ? Tn : T;
+    a0 = ok ? alpha * c0 + om * a0 : a0;
+    a1 = ok ? alpha * c1 + om * a1 : a1;
+    a2 = ok ? alpha * c2 + om * a2 : a2;
+    const float dL_dG = op * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
+    p[0] += dL_dG * (2.0f * a.z * gdx + a.w * gdy);
+    p[1] += dL_dG * (2.0f * b.x * gdy + a.w * gdx);
+    const float hg = -0.5f * dL_dG;
+    p[2] += hg * gdx * dx;
+    p[3] -= dL_dG * gdx * dy;
+    p[4] += hg * gdy * dy;
+    p[5] += G * dL_dalpha;
+    p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+    return ok;
+}
+
+template <bool EXACT, int ABL = 0>
 __global__ void __launch_bounds__(64)
 lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -599,19 +653,35 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __r
             const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
             float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             bool contrib = false;
+            if (ABL == 4) { asm volatile("" ::"v"(a.x), "v"(b.x)); continue; }
+            if (ABL == 3) {
+                contrib = rel <= last[0];
+                p[0] = a.x; p[1] = a.y; p[2] = b.x; p[8] = c.x;
+            } else {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                if (m & (1u << s)) {
-                    if (rel <= last[s])
-                        contrib |= bwd_pair<EXACT>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
-                                                   la[s], lc0[s], lc1[s], lc2[s], p);
+                for (int s = 0; s < 4; s++) {
+                    if (m & (1u << s)) {
+                        if (EXACT) {
+                            if (rel <= last[s])
+                                contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
+                                                          la[s], lc0[s], lc1[s], lc2[s], p);
+                        } else {
+                            contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s],
+                                                     a1[s], a2[s], p);
+                        }
+                    }
                 }
             }
             if (__ballot(contrib) == 0) continue;
+            if (ABL == 2) {
+                asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]));
+                continue;
+            }
             wave_reduce9_to_lds(p, stage + j * 9, lane);
             hitmask |= 1ull << j;
         }
         __builtin_amdgcn_wave_barrier();
+        if (ABL == 1) { if (stage[lane] == 12345.678f) acc[0] = 1.0f; hitmask = 0; }
         if ((hitmask >> lane) & 1ull) {
             float* dst = acc + (size_t)__float_as_uint(r2.w) * 12;
             const float* src = stage + lane * 9;
@@ -635,35 +705,52 @@ __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8 + K9 fused: per-Gaussian backward
-__global__ void __launch_bounds__(256)
+// K8 + K9 fused: per-Gaussian backward.  One wave per workgroup; SH rows in and dL/dSH rows out go
+// through LDS so that global traffic is coalesced 16-byte accesses.
+__global__ void __launch_bounds__(LG_PP)
 lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                  const int32_t* __restrict__ radii, const float* __restrict__ cov3D, const uint32_t* __restrict__ clamp,
-                  const float* __restrict__ acc, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D,
-                  float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                  float* __restrict__ dL_dscales, float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+                  const int32_t* __restrict__ radii, const float4* __restrict__ aux, const float* __restrict__ acc,
+                  float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
+                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    const uint32_t lane = threadIdx.x;
+    const int i0 = blockIdx.x * LG_PP;
+    const int i = i0 + (int)lane;
     float vm[16], pm[16], cp[3];
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    const bool vis = radii[i] > 0;
+    const bool vis = (i < N) && radii[i] > 0;
+    const uint64_t vmask = __ballot(vis);
+    const int rowf = 3 * M;
+    const int rows = min(LG_PP, N - i0);
+    const bool use_sh = (shs != nullptr) && (dL_dshs != nullptr);
+    if (use_sh && vmask) {
+        stage_sh_rows(shs, i0, rows, rowf, vmask, sh_rows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     float m2[3] = {0, 0, 0}, m3[3] = {0, 0, 0}, dop = 0.0f, dsc[3] = {0, 0, 0}, drot[4] = {0, 0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     float dcol[3] = {0, 0, 0};
-    float* dsh_row = dL_dshs ? dL_dshs + (size_t)i * M * 3 : nullptr;
+    float dsh[LG_SH_MAXF];
+#pragma unroll
+    for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = 0.0f;
     if (vis) {
         float a[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) a[k] = acc[(size_t)i * 12 + k];
+        {
+            const float4* ap = reinterpret_cast<const float4*>(acc + (size_t)i * 12);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w; a[8] = a2.x;
+        }
         const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
-        float S[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) S[k] = cov3D[6 * (size_t)i + k];
+        const float4 x0 = aux[2 * (size_t)i], x1 = aux[2 * (size_t)i + 1];
+        float S[6] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y };
         LgGradOut go;
         lg_backward_geom(vm, pm, px, py, pz, S, a, W, H, tanfovx, tanfovy, go);
         m2[0] = go.mean2D[0]; m2[1] = go.mean2D[1];
@@ -671,29 +758,62 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
         dop = a[5];
         if (colors_precomp) {
             dcol[0] = a[6]; dcol[1] = a[7]; dcol[2] = a[8];
-        } else if (shs) {
-            const uint32_t cb = clamp[i];
+        } else if (use_sh) {
+            const uint32_t cb = __float_as_uint(x1.z);
             float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
-            float sh[48];
-            const float* src = shs + (size_t)i * M * 3;
-            const int ncoef = (D + 1) * (D + 1);
-            for (int k = 0; k < 48; k++) sh[k] = (k < ncoef * 3) ? src[k] : 0.0f;
-            // zero the coefficients above the active degree, then let the store callback fill the live ones
-            for (int k = ncoef * 3; k < M * 3; k++) dsh_row[k] = 0.0f;
-            lg_backward_sh(D, sh, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh_row[k * 3 + c] = v; });
+            float sh[LG_SH_MAXF];
+            const float* row = sh_rows + lane * rowf;
+            const int nact = (D + 1) * (D + 1) * 3;
+            if ((rowf & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < LG_SH_MAXF / 4; q++) {
+                    float4 v4 = make_float4(0, 0, 0, 0);
+                    if (q * 4 < nact) v4 = reinterpret_cast<const float4*>(row)[q];
+                    sh[4 * q] = v4.x; sh[4 * q + 1] = v4.y; sh[4 * q + 2] = v4.z; sh[4 * q + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
+            }
+            lg_backward_sh(D, sh, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh[k * 3 + c] = v; });
         }
         if (cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; k++) dcov[k] = go.cov3D[k];
         } else {
-            float s[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+            float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
             const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
             float q[4] = { q4.x, q4.y, q4.z, q4.w };
-            lg_backward_cov3d(s, mod, q, go.cov3D, dsc, drot);
+            lg_backward_cov3d(sc, mod, q, go.cov3D, dsc, drot);
         }
-    } else if (dsh_row) {
-        for (int k = 0; k < M * 3; k++) dsh_row[k] = 0.0f;
     }
+    if (use_sh) {
+        // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced
+        __builtin_amdgcn_wave_barrier();
+        float* row = sh_rows + lane * rowf;
+        if ((rowf & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < LG_SH_MAXF / 4; q++)
+                if (q * 4 < rowf) reinterpret_cast<float4*>(row)[q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LG_SH_MAXF; k++)
+                if (k < rowf) row[k] = dsh[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dst = dL_dshs + (size_t)i0 * rowf;
+        const int nfl = rows * rowf;
+        if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            const int nvec = nfl >> 2;
+            for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(sh_rows)[q];
+            for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+        } else {
+            for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+        }
+    }
+    if (i >= N) return;
     dL_dmeans2D[3 * (size_t)i] = m2[0]; dL_dmeans2D[3 * (size_t)i + 1] = m2[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
     dL_dmeans3D[3 * (size_t)i] = m3[0]; dL_dmeans3D[3 * (size_t)i + 1] = m3[1]; dL_dmeans3D[3 * (size_t)i + 2] = m3[2];
     dL_dopacity[i] = dop;
@@ -712,6 +832,7 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
 {
     if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
     if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (g->N == 0) return LG_OK; // nothing to validate against: empty tensors carry no pointers
     if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
         return fail(LG_ERR_INVALID_ARGUMENT, "Please provide excatly one of either SHs or precomputed colors!");
     const bool sr = g->scales != nullptr && g->rotations != nullptr;
@@ -765,7 +886,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
         {
             ProfScope ps(prof, "preprocess", stream);
-            lg_preprocess<<<(N + 255) / 256, 256, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
+            lg_preprocess<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
                                                                 v->prefiltered, v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs,
                                                                 g->colors_precomp, g->opacities, g->scales, g->rotations,
                                                                 g->cov3D_precomp, geo, out_radii);
@@ -783,7 +904,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     }
     const int64_t R = h_R;
     g_stats.num_rendered = R;
-    g_stats.num_visible = h_counters[0];
+    g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
     if (num_rendered) *num_rendered = R;
 
     void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H).total);
@@ -795,7 +916,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (R > 0) {
         {
             ProfScope ps(prof, "duplicate", stream);
-            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.trect, geo.depth, bin.keys_in, bin.vals_in);
+            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.tinfo, bin.keys_in, bin.vals_in);
         }
         KCHECK("lg_duplicate");
         {
@@ -877,7 +998,15 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)N * 12 * sizeof(float), stream));
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
-        if (fast)
+        const char* abl_s = getenv("LG_ABLATE");
+        const int abl = abl_s ? atoi(abl_s) : 0;
+#define LAUNCH_BWD(EX, AB) lg_blend_bwd<EX, AB><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg, \
+                                                                 img.final_T, img.n_contrib, dL_dcolor, acc)
+        if (fast && abl == 1) LAUNCH_BWD(false, 1);
+        else if (fast && abl == 2) LAUNCH_BWD(false, 2);
+        else if (fast && abl == 3) LAUNCH_BWD(false, 3);
+        else if (fast && abl == 4) LAUNCH_BWD(false, 4);
+        else if (fast)
             lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, acc);
         else
@@ -887,9 +1016,9 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     KCHECK("lg_blend_bwd");
     {
         ProfScope ps(prof, "preprocess_bwd", stream);
-        lg_preprocess_bwd<<<(N + 255) / 256, 256, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
+        lg_preprocess_bwd<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
                                                                 v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs, g->colors_precomp,
-                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.cov3D, geo.clamp, acc,
+                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, acc,
                                                                 dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales,
                                                                 dL_drotations, dL_dcov3D);
     }
