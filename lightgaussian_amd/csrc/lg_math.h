@@ -229,6 +229,8 @@ LG_HD bool lg_project(const float* vm, const float* pm, float px, float py, floa
             int u1 = (int)fminf(big, fmaxf(-big, floorf((iy + hy) / (float)LG_TILE))) + 1;
             o.tx0 = t0 > o.rx0 ? t0 : o.rx0; o.tx1 = t1 < o.rx1 ? t1 : o.rx1;
             o.ty0 = u0 > o.ry0 ? u0 : o.ry0; o.ty1 = u1 < o.ry1 ? u1 : o.ry1;
+            if (o.tx0 > o.rx1) o.tx0 = o.rx1; // footprint entirely beside the rectangle: empty, but keep it a sub-rectangle
+            if (o.ty0 > o.ry1) o.ty0 = o.ry1;
             if (o.tx1 < o.tx0) o.tx1 = o.tx0;
             if (o.ty1 < o.ty0) o.ty1 = o.ty0;
             o.hx = hx; o.hy = hy;

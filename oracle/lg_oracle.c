@@ -742,3 +742,14 @@ void lgo_backward(const lgo_ctx *ctx, int N, int M, int D, int W, int H, const r
 }
 
 int lgo_real_bytes(void) { return (int)sizeof(real); }
+
+/* ---- small hooks so that tests can pin the reference-owned pieces against tests/golden ---- */
+void lgo_cov3d(int n, const real *scales, real mod, const real *rots, real *cov6)
+{
+    for (int i = 0; i < n; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov6 + 6 * i);
+}
+/* sh [n][M][3], unit dirs [n][3] -> raw SH value (no +0.5, no clamp) [n][3] */
+void lgo_sh_eval(int n, int deg, int M, const real *sh, const real *dirs, real *out)
+{
+    for (int i = 0; i < n; i++) sh_basis_eval(deg, M, sh + (size_t)i * M * 3, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], out + 3 * i);
+}
