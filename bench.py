@@ -63,12 +63,12 @@ def algorithmic_bytes(N, V, R, P, M):
         "scan": 8 * N,
         "duplicate": 12 * R,
         "sort": 24 * R,
-        "tile_ranges": 8 * R,
+        "finalize_bins": 20 * R,
         "blend_fwd": 40 * R + 20 * P,
         "blend_fwd_count": 40 * R + 20 * P + 8 * N,
         "score": 12 * N,
-        "blend_bwd": 76 * R + 20 * P,
-        "preprocess_bwd": (108 + 12 * M) * V + (92 + 12 * M) * N,
+        "blend_bwd": 88 * R + 20 * P,
+        "preprocess_bwd": (108 + 12 * M) * V + (56 + 12 * M) * N + 52 * R,
     }
 
 

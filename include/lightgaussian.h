@@ -83,11 +83,11 @@ typedef struct lg_gaussians {
 } lg_gaussians;
 
 /* Scratch sizing.  geom: per-Gaussian projected state; img: per-pixel state; binning: (tile,Gaussian)
- * instance lists for `num_rendered` instances; backward scratch: per-Gaussian gradient accumulators. */
+ * instance lists for `num_rendered` instances; backward scratch: one 48-byte gradient row per instance. */
 size_t lg_geom_bytes(int32_t N);
 size_t lg_img_bytes(int32_t width, int32_t height);
 size_t lg_binning_bytes(int64_t num_rendered, int32_t width, int32_t height);
-size_t lg_backward_scratch_bytes(int32_t N);
+size_t lg_backward_scratch_bytes(int32_t N, int64_t num_rendered);
 
 /* Called once per forward, after the instance count is known, to obtain the binning buffer
  * (same role as the resize-callbacks of the published extension). Must return a device pointer
@@ -122,7 +122,7 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  *   dL_dmeans2D [N,3] (NDC units, z = 0; consumed by scene/gaussian_model.py:784-788)
  *   dL_dmeans3D [N,3]  dL_dshs [N,M,3]  dL_dcolors [N,3]  dL_dopacity [N,1]
  *   dL_dscales [N,3]   dL_drotations [N,4]  dL_dcov3D [N,6]
- *   scratch: lg_backward_scratch_bytes(N)
+ *   scratch: lg_backward_scratch_bytes(N, num_rendered)
  */
 int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii, const void* geom, const void* binning,
                 const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,

@@ -74,7 +74,7 @@ def load():
     lib.lg_geom_bytes.restype = C.c_size_t; lib.lg_geom_bytes.argtypes = [C.c_int32]
     lib.lg_img_bytes.restype = C.c_size_t; lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.lg_binning_bytes.restype = C.c_size_t; lib.lg_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
-    lib.lg_backward_scratch_bytes.restype = C.c_size_t; lib.lg_backward_scratch_bytes.argtypes = [C.c_int32]
+    lib.lg_backward_scratch_bytes.restype = C.c_size_t; lib.lg_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
     lib.lg_forward.restype = C.c_int
     lib.lg_forward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, ALLOC_FN, vp, vp, vp, P(vp), P(C.c_int64), vp]
     lib.lg_forward_count.restype = C.c_int

@@ -5,7 +5,7 @@
 //   K2 inclusive scan     (rocPRIM)    : instance offsets, R = total instances
 //   K3 lg_duplicate       per Gaussian : (tile<<32 | depth bits, id) for every tile of the tight rectangle
 //   K4 radix sort         (rocPRIM)    : stable, by (tile, depth); ties keep Gaussian-id order
-//   K5 lg_tile_ranges     per instance : [start,end) of every tile
+//   K5 lg_finalize_bins   per instance : [start,end) of every tile, sorted Gaussian ids, slot->position map
 //   K6 lg_blend_fwd       per tile     : 4 autonomous waves (8x8 pixels each); each wave compacts the
 //                                        Gaussians overlapping ITS 8x8 block into an LDS queue and blends
 //                                        front-to-back; wave-ballot early termination; count variant
@@ -130,7 +130,11 @@ static ImgView carve_img(void* base, int W, int H)
 }
 
 struct BinView {
-    uint64_t *keys_in, *keys_out; uint32_t *vals_in, *vals_out; uint2* ranges;
+    uint64_t *keys_in, *keys_out;   // [R] tile<<32 | depth bits (radix-sort double buffer)
+    uint32_t *slot_in, *slot_out;   // [R] pre-sort slot index (iota) / slots in sorted order
+    uint32_t* gid_slot;             // [R] Gaussian id of every pre-sort slot
+    uint32_t* point_list;           // [R] Gaussian ids in sorted order (what the blend kernels walk)
+    uint2* ranges;                  // [tiles]
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
 static int key_bits_for(int ntiles)
@@ -147,8 +151,10 @@ static BinView carve_bin(void* base, int64_t R, int W, int H)
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
     v.keys_in = (uint64_t*)take(n * 8);
     v.keys_out = (uint64_t*)take(n * 8);
-    v.vals_in = (uint32_t*)take(n * 4);
-    v.vals_out = (uint32_t*)take(n * 4);
+    v.slot_in = (uint32_t*)take(n * 4);
+    v.slot_out = (uint32_t*)take(n * 4);
+    v.gid_slot = (uint32_t*)take(n * 4);
+    v.point_list = (uint32_t*)take(n * 4);
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
     size_t tb = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
@@ -162,7 +168,11 @@ static BinView carve_bin(void* base, int64_t R, int W, int H)
 extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
 extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
 extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H) { return carve_bin(nullptr, R, W, H).total; }
-extern "C" size_t lg_backward_scratch_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * 12 * sizeof(float)); }
+extern "C" size_t lg_backward_scratch_bytes(int32_t N, int64_t R)
+{
+    (void)N;
+    return align_up((size_t)(R > 0 ? R : 1) * 12 * sizeof(float)); // one 48-byte gradient row per (tile, Gaussian) instance
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -310,7 +320,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 // K3: duplicate with keys
 __global__ void __launch_bounds__(256)
 lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             const uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+             const uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ slots,
+             uint32_t* __restrict__ gid_slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -323,17 +334,20 @@ lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
-            vals[off] = (uint32_t)i;
+            slots[off] = off;
+            gid_slot[off] = (uint32_t)i;
             off++;
         }
 }
 
-// K5: tile ranges from sorted keys
+// K5: per sorted position: tile ranges and the Gaussian id (point_list)
 __global__ void __launch_bounds__(256)
-lg_tile_ranges(uint32_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+lg_finalize_bins(uint32_t R, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slot_sorted,
+                 const uint32_t* __restrict__ gid_slot, uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
+    point_list[i] = gid_slot[slot_sorted[i]];
     const uint32_t t = (uint32_t)(keys[i] >> 32);
     if (i == 0) ranges[t].x = 0;
     else {
@@ -586,9 +600,9 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 template <bool EXACT, int ABL = 0>
 __global__ void __launch_bounds__(64)
 lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
-             const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-             float* __restrict__ acc)
+             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_sorted, const float4* __restrict__ rec,
+             const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+             const float* __restrict__ dL_dpix, float* __restrict__ part)
 {
     __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
@@ -622,71 +636,82 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __r
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
-    if (wmax == 0) return;
     const uint32_t n_list = range.y - range.x;
+    if (n_list == 0) return;
     if (wmax > n_list) wmax = n_list;
     const float tbx = (float)(tx * LG_TILE), tby = (float)(ty * LG_TILE);
+    float4* rows = reinterpret_cast<float4*>(part);
 
-    for (int k = (int)((wmax - 1) / LG_Q); k >= 0; k--) {
+    // every list entry of the tile writes exactly one 48-byte row (zeros when nothing contributed) at its
+    // PRE-SORT slot, where the rows of one Gaussian are contiguous: no zero-fill pass, no atomics, and K9
+    // reads its rows sequentially and sums them in a fixed order (deterministic gradients)
+    for (int k = (int)((n_list - 1) / LG_Q); k >= 0; k--) {
         const uint32_t base = range.x + (uint32_t)k * LG_Q;
-        const uint32_t nb = min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q); // entries of this batch (uniform)
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
-        if (lane < nb) {
-            const uint32_t id = point_list[base + lane];
-            r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
-            uint32_t m = 0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
-                const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
-                m |= (hit ? 1u : 0u) << s;
-            }
-            q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
-        }
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t nbt = min((uint32_t)LG_Q, n_list - (uint32_t)k * LG_Q);                             // entries of this batch
+        const uint32_t nb = wmax > (uint32_t)k * LG_Q ? min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q) : 0u; // ... that any pixel reached
         uint64_t hitmask = 0;
-        for (int j = (int)nb - 1; j >= 0; j--) {
-            const float4 c = q2[j];
-            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            if (m == 0) continue;
-            const float4 a = q0[j], b = q1[j];
-            const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
-            float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            bool contrib = false;
-            if (ABL == 4) { asm volatile("" ::"v"(a.x), "v"(b.x)); continue; }
-            if (ABL == 3) {
-                contrib = rel <= last[0];
-                p[0] = a.x; p[1] = a.y; p[2] = b.x; p[8] = c.x;
-            } else {
+        if (nb > 0) {
+            float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            if (lane < nb) {
+                const uint32_t id = point_list[base + lane];
+                r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+                uint32_t m = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if (m & (1u << s)) {
-                        if (EXACT) {
-                            if (rel <= last[s])
-                                contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
-                                                          la[s], lc0[s], lc1[s], lc2[s], p);
-                        } else {
-                            contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s],
-                                                     a1[s], a2[s], p);
+                    const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
+                    const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
+                    m |= (hit ? 1u : 0u) << s;
+                }
+                q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int j = (int)nb - 1; j >= 0; j--) {
+                const float4 c = q2[j];
+                const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+                if (m == 0) continue;
+                const float4 a = q0[j], b = q1[j];
+                const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
+                float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                bool contrib = false;
+                if (ABL == 4) { asm volatile("" ::"v"(a.x), "v"(b.x)); continue; }
+                if (ABL == 3) {
+                    contrib = rel <= last[0];
+                    p[0] = a.x; p[1] = a.y; p[2] = b.x; p[8] = c.x;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        if (m & (1u << s)) {
+                            if (EXACT) {
+                                if (rel <= last[s])
+                                    contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
+                                                              la[s], lc0[s], lc1[s], lc2[s], p);
+                            } else {
+                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s],
+                                                         a1[s], a2[s], p);
+                            }
                         }
                     }
                 }
+                if (__ballot(contrib) == 0) continue;
+                if (ABL == 2) {
+                    asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]));
+                    continue;
+                }
+                wave_reduce9_to_lds(p, stage + j * 9, lane);
+                hitmask |= 1ull << j;
             }
-            if (__ballot(contrib) == 0) continue;
-            if (ABL == 2) {
-                asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]));
-                continue;
-            }
-            wave_reduce9_to_lds(p, stage + j * 9, lane);
-            hitmask |= 1ull << j;
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        if (ABL == 1) { if (stage[lane] == 12345.678f) acc[0] = 1.0f; hitmask = 0; }
-        if ((hitmask >> lane) & 1ull) {
-            float* dst = acc + (size_t)__float_as_uint(r2.w) * 12;
-            const float* src = stage + lane * 9;
-#pragma unroll
-            for (int c9 = 0; c9 < 9; c9++) atomicAdd(dst + c9, src[c9]);
+        if (ABL != 1 && lane < nbt) {
+            float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0;
+            if ((hitmask >> lane) & 1ull) {
+                const float* src = stage + lane * 9;
+                o0 = make_float4(src[0], src[1], src[2], src[3]);
+                o1 = make_float4(src[4], src[5], src[6], src[7]);
+                o2 = make_float4(src[8], 0.0f, 0.0f, 0.0f);
+            }
+            float4* dst = rows + 3 * (size_t)slot_sorted[base + lane];
+            dst[0] = o0; dst[1] = o1; dst[2] = o2;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -712,7 +737,8 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                  const int32_t* __restrict__ radii, const float4* __restrict__ aux, const float* __restrict__ acc,
+                  const int32_t* __restrict__ radii, const float4* __restrict__ aux, const uint32_t* __restrict__ touched,
+                  const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                   float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
                   float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
@@ -742,11 +768,16 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
 #pragma unroll
     for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = 0.0f;
     if (vis) {
-        float a[9];
+        // gather this Gaussian's gradient rows (one per tile instance) in slot order: deterministic, no atomics
+        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         {
-            const float4* ap = reinterpret_cast<const float4*>(acc + (size_t)i * 12);
-            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w; a[8] = a2.x;
+            const uint32_t t = touched[i];
+            const uint32_t u0 = offsets[i] - t;
+            for (uint32_t u = u0; u < u0 + t; u++) {
+                const float4* rp = part + 3 * (size_t)u;
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w; a[8] += v2.x;
+            }
         }
         const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
         const float4 x0 = aux[2 * (size_t)i], x1 = aux[2 * (size_t)i + 1];
@@ -912,24 +943,25 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (binning_out) *binning_out = bin_p;
     BinView bin = carve_bin(bin_p, R, W, H);
     HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
-    const uint32_t* point_list = bin.vals_out;
+    const uint32_t* point_list = bin.point_list;
     if (R > 0) {
         {
             ProfScope ps(prof, "duplicate", stream);
-            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.tinfo, bin.keys_in, bin.vals_in);
+            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.tinfo, bin.keys_in, bin.slot_in, bin.gid_slot);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.vals_in, bin.vals_out, (int)R, 0,
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
                                                        key_bits_for(ntiles), stream));
         }
         {
-            ProfScope ps(prof, "tile_ranges", stream);
-            lg_tile_ranges<<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, bin.keys_out, bin.ranges);
+            ProfScope ps(prof, "finalize_bins", stream);
+            lg_finalize_bins<<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, bin.keys_out, bin.slot_out, bin.gid_slot,
+                                                                              bin.point_list, bin.ranges);
         }
-        KCHECK("lg_tile_ranges");
+        KCHECK("lg_finalize_bins");
     }
     if (count && N > 0) {
         HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
@@ -994,23 +1026,22 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H);
-    float* acc = (float*)scratch;
-    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)N * 12 * sizeof(float), stream));
+    float* acc = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         const char* abl_s = getenv("LG_ABLATE");
         const int abl = abl_s ? atoi(abl_s) : 0;
-#define LAUNCH_BWD(EX, AB) lg_blend_bwd<EX, AB><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg, \
+#define LAUNCH_BWD(EX, AB) lg_blend_bwd<EX, AB><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg, \
                                                                  img.final_T, img.n_contrib, dL_dcolor, acc)
         if (fast && abl == 1) LAUNCH_BWD(false, 1);
         else if (fast && abl == 2) LAUNCH_BWD(false, 2);
         else if (fast && abl == 3) LAUNCH_BWD(false, 3);
         else if (fast && abl == 4) LAUNCH_BWD(false, 4);
         else if (fast)
-            lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+            lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, acc);
         else
-            lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.vals_out, geo.rec, v->bg,
+            lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                 img.final_T, img.n_contrib, dL_dcolor, acc);
     }
     KCHECK("lg_blend_bwd");
@@ -1018,7 +1049,8 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
         ProfScope ps(prof, "preprocess_bwd", stream);
         lg_preprocess_bwd<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
                                                                 v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs, g->colors_precomp,
-                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, acc,
+                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched, geo.offsets,
+                                                                reinterpret_cast<const float4*>(acc),
                                                                 dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales,
                                                                 dL_drotations, dL_dcov3D);
     }

@@ -180,7 +180,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sc = torch.empty((N, 3), **f32) if call.scales is not None else None
             g_rot = torch.empty((N, 4), **f32) if call.rots is not None else None
             g_cov = torch.empty((N, 6), **f32) if call.cov is not None else None
-            scratch = torch.empty(lib.lg_backward_scratch_bytes(N), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
             rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
                                  C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
                                  _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov),

@@ -39,8 +39,8 @@ def test_library_built_loads_and_exports_every_declared_symbol():
     lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     assert lib.lg_img_bytes(1920, 1080) >= 1920 * 1080 * 8
     lib.lg_backward_scratch_bytes.restype = C.c_size_t
-    lib.lg_backward_scratch_bytes.argtypes = [C.c_int32]
-    assert lib.lg_backward_scratch_bytes(1000) >= 1000 * 9 * 4
+    lib.lg_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
+    assert lib.lg_backward_scratch_bytes(1000, 5000) >= 5000 * 9 * 4
 
 
 def test_struct_layout_matches_header():
