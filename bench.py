@@ -61,8 +61,8 @@ def algorithmic_bytes(N, V, R, P, M):
     return {
         "preprocess": 16 * N + (76 + 12 * M + 28) * V,
         "scan": 8 * N,
-        "duplicate": 12 * R,
-        "sort": 24 * R,
+        "duplicate": 8 * R,
+        "sort": 16 * R,
         "finalize_bins": 20 * R,
         "blend_fwd": 40 * R + 20 * P,
         "blend_fwd_count": 40 * R + 20 * P + 8 * N,

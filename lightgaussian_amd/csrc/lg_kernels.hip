@@ -87,7 +87,8 @@ struct GeomView {
     uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
     uint32_t* touched;  // [N]
     uint32_t* offsets;  // [N] inclusive scan of touched
-    uint32_t* counters; // [16]: 0 = visible count, 1 = prefiltered violation
+    uint32_t* counters; // [16]: 1 = prefiltered violation, 2 = largest depth bit pattern
+    uint32_t* blk_dmax; // [ceil(N/64)] per-workgroup largest depth bit pattern (reduced by lg_reduce_dmax)
     void* scan_temp; size_t scan_temp_bytes;
     size_t total;
 };
@@ -112,6 +113,7 @@ static GeomView carve_geom(void* base, int N)
     g.touched = (uint32_t*)take(n * 4);
     g.offsets = (uint32_t*)take(n * 4);
     g.counters = (uint32_t*)take(64);
+    g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
     g.scan_temp_bytes = scan_temp_bytes_for((int)n);
     g.scan_temp = take(g.scan_temp_bytes);
     g.total = off;
@@ -129,36 +131,43 @@ static ImgView carve_img(void* base, int W, int H)
     return v;
 }
 
+// Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
+// offsets for both key formats.
 struct BinView {
-    uint64_t *keys_in, *keys_out;   // [R] tile<<32 | depth bits (radix-sort double buffer)
-    uint32_t *slot_in, *slot_out;   // [R] pre-sort slot index (iota) / slots in sorted order
-    uint32_t* gid_slot;             // [R] Gaussian id of every pre-sort slot
-    uint32_t* point_list;           // [R] Gaussian ids in sorted order (what the blend kernels walk)
     uint2* ranges;                  // [tiles]
+    uint32_t* point_list;           // [R] Gaussian ids in (tile, depth, id) order
+    uint32_t* slot_out;             // [R] pre-sort slot of every sorted position (row address of the backward)
+    uint64_t *keys_in, *keys_out;   // [R] radix-sort double buffer
+    uint32_t* slot_in;              // [R] (pairs format only) iota values carried through the sort
+    uint32_t* gid_slot;             // [R] (pairs format only) Gaussian id of every pre-sort slot
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
-static int key_bits_for(int ntiles)
+static int bits_for(uint32_t n) // smallest b with 2^b >= n
 {
     int b = 0;
-    while ((1 << b) < ntiles) b++;
-    return 32 + b;
+    while (b < 32 && (1ull << b) < n) b++;
+    return b;
 }
-static BinView carve_bin(void* base, int64_t R, int W, int H)
+static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
 {
-    BinView v; size_t off = 0; char* p = (char*)base;
+    BinView v; memset(&v, 0, sizeof(v)); size_t off = 0; char* p = (char*)base;
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     size_t n = (size_t)(R > 0 ? R : 1);
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
+    v.ranges = (uint2*)take((size_t)gx * gy * 8);
+    v.point_list = (uint32_t*)take(n * 4);
+    v.slot_out = (uint32_t*)take(n * 4);
     v.keys_in = (uint64_t*)take(n * 8);
     v.keys_out = (uint64_t*)take(n * 8);
-    v.slot_in = (uint32_t*)take(n * 4);
-    v.slot_out = (uint32_t*)take(n * 4);
-    v.gid_slot = (uint32_t*)take(n * 4);
-    v.point_list = (uint32_t*)take(n * 4);
-    v.ranges = (uint2*)take((size_t)gx * gy * 8);
     size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (int)n, 0, key_bits_for(gx * gy));
+    if (packed) {
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 64);
+    } else {
+        v.slot_in = (uint32_t*)take(n * 4);
+        v.gid_slot = (uint32_t*)take(n * 4);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                                 (uint32_t*)nullptr, (int)n, 0, 64);
+    }
     v.sort_temp_bytes = tb;
     v.sort_temp = take(tb);
     v.total = off;
@@ -167,7 +176,11 @@ static BinView carve_bin(void* base, int64_t R, int W, int H)
 
 extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
 extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
-extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H) { return carve_bin(nullptr, R, W, H).total; }
+extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H)
+{
+    const size_t a = carve_bin(nullptr, R, W, H, true).total, b = carve_bin(nullptr, R, W, H, false).total;
+    return a > b ? a : b; // upper bound over both key formats
+}
 extern "C" size_t lg_backward_scratch_bytes(int32_t N, int64_t R)
 {
     (void)N;
@@ -314,14 +327,43 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
         g.touched[i] = touched;
     }
     // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
+    // largest depth of the workgroup (bit pattern; positive floats order like integers), for the packed sort key.
+    // Written per workgroup and reduced by a one-block kernel: a shared atomicMax serialises the first ~3k waves.
+    uint32_t dmax = vis ? __float_as_uint(sp.depth) : 0u;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, sh));
+    if (lane == 0) g.blk_dmax[blockIdx.x] = dmax;
 }
 
 // ------------------------------------------------------------------------------------------------
+// max over the per-workgroup depth maxima -> counters[2]
+__global__ void __launch_bounds__(1024)
+lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t wmax[16];
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < nblk; i += 1024) m = max(m, blk_dmax[i]);
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
+        counters[2] = m;
+    }
+}
+
 // K3: duplicate with keys
+// Key formats.  PACKED: tile | (depth bits - bias) | Gaussian id in one u64, sorted keys-only on the tile+depth
+// bits: the stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free
+// (5 passes x 16 B instead of 6 x 24 B).  PAIRS (fallback when the fields do not fit 64 bits): tile<<32 | depth
+// with the pre-sort slot as value.
+#define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
+
+template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             const uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ slots,
-             uint32_t* __restrict__ gid_slot)
+lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
+             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ slots, uint32_t* __restrict__ gid_slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -330,28 +372,49 @@ lg_duplicate(int N, int gx, const uint32_t* __restrict__ touched, const uint32_t
     uint32_t off = offsets[i] - t;
     const uint4 r = tinfo[i];
     const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
-    const uint64_t d = (uint64_t)r.z;
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
-            slots[off] = off;
-            gid_slot[off] = (uint32_t)i;
-            off++;
-        }
+    if (PACKED) {
+        tinfo[i].w = off; // slot base, read back by lg_finalize_bins
+        const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
+        const int sh = depth_bits + gid_bits;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) keys[off++] = ((uint64_t)(uint32_t)(y * gx + x) << sh) | low;
+    } else {
+        const uint64_t d = (uint64_t)r.z;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
+                slots[off] = off;
+                gid_slot[off] = (uint32_t)i;
+                off++;
+            }
+    }
 }
 
-// K5: per sorted position: tile ranges and the Gaussian id (point_list)
+// K5: per sorted position: tile ranges, Gaussian id (point_list) and pre-sort slot
+template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_finalize_bins(uint32_t R, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slot_sorted,
-                 const uint32_t* __restrict__ gid_slot, uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+lg_finalize_bins(uint32_t R, int gx, int depth_bits, int gid_bits, const uint64_t* __restrict__ keys, const uint4* __restrict__ tinfo,
+                 const uint32_t* __restrict__ slot_sorted, const uint32_t* __restrict__ gid_slot, uint32_t* __restrict__ point_list,
+                 uint32_t* __restrict__ slot_out, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
-    point_list[i] = gid_slot[slot_sorted[i]];
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    const int tsh = PACKED ? depth_bits + gid_bits : 32;
+    const uint64_t key = keys[i];
+    const uint32_t t = (uint32_t)(key >> tsh);
+    if (PACKED) {
+        const uint32_t gid = (uint32_t)(key & ((1ull << gid_bits) - 1ull));
+        const uint4 r = tinfo[gid];
+        const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF;
+        const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
+        point_list[i] = gid;
+        slot_out[i] = r.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    } else {
+        point_list[i] = gid_slot[slot_sorted[i]]; // slot_out was written by the sort itself
+    }
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+        const uint32_t tp = (uint32_t)(keys[i - 1] >> tsh);
         if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
     }
     if (i == R - 1) ranges[t].y = R;
@@ -912,7 +975,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 
     if (binning_out) *binning_out = nullptr;
     if (num_rendered) *num_rendered = 0;
-    uint32_t h_counters[2] = {0, 0}, h_R = 0;
+    uint32_t h_counters[3] = {0, 0, 0}, h_R = 0;
     if (N > 0) {
         HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
         {
@@ -923,13 +986,15 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
                                                                 g->cov3D_precomp, geo, out_radii);
         }
         KCHECK("lg_preprocess");
+        lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.counters);
+        KCHECK("lg_reduce_dmax");
         {
             ProfScope ps(prof, "scan", stream);
             size_t tb = geo.scan_temp_bytes;
             HIP_TRY(hipcub::DeviceScan::InclusiveSum(geo.scan_temp, tb, geo.touched, geo.offsets, N, stream));
         }
         HIP_TRY(hipMemcpyAsync(&h_R, geo.offsets + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_counters, geo.counters, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_counters, geo.counters, 12, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
@@ -938,28 +1003,49 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
     if (num_rendered) *num_rendered = R;
 
-    void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H).total);
+    // key format: packed single-u64 keys when tile | depth | id fit 64 bits (they do for every BASELINE config)
+    const int tile_bits = bits_for((uint32_t)ntiles), gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
+    const uint32_t dspan = h_counters[2] > LG_DEPTH_BIAS ? h_counters[2] - LG_DEPTH_BIAS : 0u;
+    const int depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
+    const bool packed = (tile_bits + depth_bits + gid_bits <= 64) && (getenv("LG_FORCE_PAIR_SORT") == nullptr);
+
+    void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, packed).total);
     if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
     if (binning_out) *binning_out = bin_p;
-    BinView bin = carve_bin(bin_p, R, W, H);
+    BinView bin = carve_bin(bin_p, R, W, H, packed);
     HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
     const uint32_t* point_list = bin.point_list;
     if (R > 0) {
         {
             ProfScope ps(prof, "duplicate", stream);
-            lg_duplicate<<<(N + 255) / 256, 256, 0, stream>>>(N, gx, geo.touched, geo.offsets, geo.tinfo, bin.keys_in, bin.slot_in, bin.gid_slot);
+            if (packed)
+                lg_duplicate<true><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, depth_bits, gid_bits, geo.touched, geo.offsets, geo.tinfo,
+                                                                        bin.keys_in, nullptr, nullptr);
+            else
+                lg_duplicate<false><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, 0, 0, geo.touched, geo.offsets, geo.tinfo, bin.keys_in,
+                                                                         bin.slot_in, bin.gid_slot);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
-                                                       key_bits_for(ntiles), stream));
+            if (packed)
+                HIP_TRY(hipcub::DeviceRadixSort::SortKeys(bin.sort_temp, tb, bin.keys_in, bin.keys_out, (int)R, gid_bits,
+                                                          gid_bits + depth_bits + tile_bits, stream));
+            else
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
+                                                           32 + tile_bits, stream));
         }
         {
             ProfScope ps(prof, "finalize_bins", stream);
-            lg_finalize_bins<<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, bin.keys_out, bin.slot_out, bin.gid_slot,
-                                                                              bin.point_list, bin.ranges);
+            if (packed)
+                lg_finalize_bins<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, depth_bits, gid_bits, bin.keys_out,
+                                                                                        geo.tinfo, nullptr, nullptr, bin.point_list,
+                                                                                        bin.slot_out, bin.ranges);
+            else
+                lg_finalize_bins<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, 0, 0, bin.keys_out, geo.tinfo,
+                                                                                         bin.slot_out, bin.gid_slot, bin.point_list,
+                                                                                         bin.slot_out, bin.ranges);
         }
         KCHECK("lg_finalize_bins");
     }
@@ -1025,7 +1111,7 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
-    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H);
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
     float* acc = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);

@@ -106,6 +106,38 @@ def test_backward_parity_canonical_arithmetic():
         rasterizer.set_option("fast_exp", True)
 
 
+def test_packed_key_sort_equals_pair_sort_fallback():
+    """Sort key formats: packed tile|depth|id u64 keys sorted keys-only on the tile+depth bits (default) vs
+    (tile<<32|depth, slot) pairs (fallback when the fields do not fit 64 bits).  Same (tile, depth, id) order
+    => bit-identical outputs and gradients."""
+    import os
+    import gpu_common
+    gimg = np.random.RandomState(5).randn(3, CASES[2]["H"], CASES[2]["W"]).astype(np.float32)
+    res = {}
+    for mode in ("tile", "global"):
+        if mode == "global":
+            os.environ["LG_FORCE_PAIR_SORT"] = "1"
+        try:
+            res[mode] = (gpu_common.hip_forward_backward(_scene(CASES[2]), count=True),
+                         gpu_common.hip_forward_backward(_scene(CASES[2]), grad_image=gimg))
+        finally:
+            os.environ.pop("LG_FORCE_PAIR_SORT", None)
+    a, b = res["tile"], res["global"]
+    assert np.array_equal(a[0]["count"], b[0]["count"]) and np.array_equal(a[0]["color"], b[0]["color"])
+    assert np.array_equal(a[0]["score"], b[0]["score"])
+    for name in a[1]["grads"]:
+        assert np.array_equal(a[1]["grads"][name], b[1]["grads"][name]), name   # rows + fixed-order gather: deterministic
+
+
+def test_gradients_are_run_to_run_deterministic():
+    import gpu_common
+    gimg = np.random.RandomState(6).randn(3, CASES[1]["H"], CASES[1]["W"]).astype(np.float32)
+    a = gpu_common.hip_forward_backward(_scene(CASES[1]), grad_image=gimg)
+    b = gpu_common.hip_forward_backward(_scene(CASES[1]), grad_image=gimg)
+    for name in a["grads"]:
+        assert np.array_equal(a["grads"][name], b["grads"][name]), name
+
+
 def test_packed_wave_reduction():
     """The permlane-swap reduction of the backward blend: 9 values x 64 lanes -> 9 sums."""
     import ctypes as C
