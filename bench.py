@@ -9,8 +9,8 @@ Gaussians (SURVEY.md section 8d generator, seed 20250103), 1920x1080, SH degree 
 view through the reference's own boundary: gaussian_renderer.render() (getters + rasterizer
 forward) -> L1 loss vs a ground-truth image -> backward to the raw GaussianModel parameters
 (rasterizer backward + getter backward).  No optimizer step: it is not part of the path.
-`--mode fwd` times render() only, `--mode count` times count_render() (+ the sharded
-significance reduction when N > 1).
+`--mode fwd` times render() only; `--mode count` times the significance pass of config C4
+(prune_list_sharded: count_render per view, getters evaluated once, RCCL reduction at the end).
 
 Multi-GPU: one process per GPU, Gaussians replicated, cameras sharded (rank r renders views
 r, r+N, ...): weak scaling, no data-path collective in fwd/fwdbwd; `count` ends with the RCCL
@@ -139,35 +139,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if args.mode == "count" and world > 1:
-        pass  # the per-view loop above is the sharded body; the reduction is timed below
-    barrier()
-    elapsed = time.perf_counter() - t0
+    extra = {}
+    if args.mode == "count":
+        # the significance pass of config C4: every rank renders `steps` views of a (steps*world)-camera list with
+        # count_render, then the RCCL reduction (int all-reduce + ordered score exchange); getters evaluated once
+        def cam_list(n):
+            return [syn.orbit_camera(k % args.views, args.views, W, H).to(dev) for k in range(n)]
+        with torch.no_grad():
+            prune_list_sharded(pc, cam_list(max(args.warmup, 1) * world), pipe, bg, force_collectives=world > 1)
+        cl = cam_list(args.steps * world)
+        barrier()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        extra["significance_pass"] = {"views": args.steps * world, "seconds": round(elapsed, 4),
+                                      "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item())}
+    else:
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed  # whole-job views/s: every rank did `steps` views
-
-    extra = {}
-    if args.mode == "count" and world > 1:
-        # the collective of the sharded prune pass (config C4), timed separately: counts all-reduce + ordered score exchange
-        class _Cams:
-            def __init__(self, c): self.c = c
-            def getTrainCameras(self): return self.c
-        sub = [syn.orbit_camera(k, args.views, W, H).to(dev) for k in range(min(args.views, 2 * world))]
-        barrier(); t1 = time.perf_counter()
-        with torch.no_grad():
-            prune_list_sharded(pc, _Cams(sub), pipe, bg)
-        barrier()
-        extra["sharded_prune_pass_s_for_%d_views" % len(sub)] = time.perf_counter() - t1
 
     result = None
     if rank == 0:

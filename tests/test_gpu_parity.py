@@ -206,3 +206,30 @@ def test_full_size_properties():
     for i in idx:
         assert np.float32(out["score"][i]).tobytes() == np.float32(oracle.seqsum(op[i], int(out["count"][i]))).tobytes()
     assert ((out["radii"] > 0) | (out["count"] == 0)).all()
+
+
+def test_sharded_prune_pass_collectives_on_rccl():
+    """prune_list_sharded through the real RCCL code path (backend nccl) at world size 1 with the collectives
+    forced: int all-reduce, all_to_all_single, all_gather_into_tensor on device tensors.  Must equal the plain loop."""
+    import socket
+    import torch.distributed as dist
+    from lightgaussian_amd import prune as lg_prune
+    from lightgaussian_amd.gaussian_renderer import count_render
+    dev = torch.device("cuda:0")
+    g = syn.make_gaussians(4000, seed=13, log_scale_mean=math.log(0.04), opacity_mean=0.5, extent=(2, 1.2, 2)).to(dev)
+    cams = [syn.orbit_camera(k, 5, 96, 64, radius=5.0).to(dev) for k in range(5)]
+    bg = torch.zeros(3, device=dev)
+    pipe = syn.PipelineParams()
+    with torch.no_grad():
+        c1, s1 = lg_prune.prune_list(g, cams, pipe, bg)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        for mode in ("ordered", "allreduce"):
+            with torch.no_grad():
+                c2, s2 = lg_prune.prune_list_sharded(g, cams, pipe, bg, mode=mode, force_collectives=True)
+            assert torch.equal(c1, c2) and torch.equal(s1, s2), mode
+    finally:
+        dist.destroy_process_group()
+    m = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, s1, 0.1))
+    assert 0 < int(m.sum()) < 4000
