@@ -211,6 +211,20 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                               "algorithmic_bytes_per_launch": ab.get(dom, 0), "avg_launch_ms": round(per_kernel[dom]["avg_ms"], 4)}
+        # HBM traffic of the dominant kernel from the committed PMC passes (tools/gpu_traffic.sh: FETCH_SIZE and WRITE_SIZE
+        # in separate rocprofv3 --pmc runs; FETCH_SIZE doubled per the gfx950 wide-read correction, which our own
+        # calibration on lg_preprocess_bwd confirms: WRITE_SIZE matches the known 744 MB of stores exactly, raw
+        # FETCH_SIZE is 0.57x the known reads).  null when no PMC file for this workload is present.
+        try:
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic_fwdbwd.json")
+            tj = json.load(open(tpath))
+            key = {"blend_bwd": "lg_blend_bwd", "blend_fwd": "lg_blend_fwd", "blend_fwd_count": "lg_blend_fwd", "preprocess": "lg_preprocess",
+                   "preprocess_bwd": "lg_preprocess_bwd"}.get(dom)
+            if key in tj and args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080):
+                result["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch_high"]
+                result["roofline"]["traffic_source"] = "profiles/r01_traffic_fwdbwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+        except Exception:
+            pass
         result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
         tot_bytes = sum(ab[k] * per_kernel[k]["launches_per_step"] for k in per_kernel if k in ab)
         result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
