@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--views", type=int, default=200, help="cameras on the orbit; steps cycle through them")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
+    ap.add_argument("--fused", action="store_true", help="render_fused (SURVEY 8f row 1 extension): getters inside the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-n", type=int, default=0, help="Gaussians in the CPU sample (0 = same as workload)")
@@ -90,7 +91,9 @@ def main():
 
     from lightgaussian_amd import _lib, synthetic as syn
     from lightgaussian_amd import rasterizer
-    from lightgaussian_amd.gaussian_renderer import render, count_render
+    from lightgaussian_amd.gaussian_renderer import render, count_render, render_fused
+    if args.fused:
+        render = render_fused
     from lightgaussian_amd.prune import prune_list_sharded
 
     _lib.load()
@@ -188,6 +191,7 @@ def main():
                                    f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
+                       "getters": "fused into K1/K9 (render_fused, SURVEY 8f-1 extension)" if args.fused else "torch (reference render() call pattern)",
                        "parallelism": f"camera-shard x{world}"},
         }
         result.update(extra)

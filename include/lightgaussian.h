@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 1
+#define LG_ABI_VERSION 2
 
 enum {
     LG_OK = 0,
@@ -50,7 +50,11 @@ enum {
     LG_FLAG_FAST_EXP = 2,  /* hardware exp/rcp in the blend kernels (training renders): image/gradients agree with the
                               canonical path to ~1e-6, far inside the 1e-4 contract; never used for count renders,
                               whose integer outputs are bit-pinned */
-    LG_FLAG_PROFILE = 4    /* record per-kernel hipEvent timings, read back with lg_profile_read() */
+    LG_FLAG_PROFILE = 4,   /* record per-kernel hipEvent timings, read back with lg_profile_read() */
+    LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
+                              activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
+                              rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc
+                              [N,1,3] with shs_rest = _features_rest [N,M-1,3] (no torch.cat).  Gradients are w.r.t. the raw tensors. */
 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:52-66), minus f_count which selects the entry point */
@@ -80,6 +84,7 @@ typedef struct lg_gaussians {
     const float* scales;         /* [N,3]   or NULL */
     const float* rotations;      /* [N,4]   or NULL   (r,x,y,z) */
     const float* cov3D_precomp;  /* [N,6]   or NULL   (exactly one of scales+rotations / cov3D_precomp) */
+    const float* shs_rest;       /* [N,M-1,3] or NULL; only with LG_FLAG_RAW_PARAMS (then shs is [N,1,3]) */
 } lg_gaussians;
 
 /* Scratch sizing.  geom: per-Gaussian projected state; img: per-pixel state; binning: (tile,Gaussian)
@@ -121,13 +126,13 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  * Gaussians that were not rasterised.  Output pointers may be NULL when the matching input was NULL.
  *   dL_dmeans2D [N,3] (NDC units, z = 0; consumed by scene/gaussian_model.py:784-788)
  *   dL_dmeans3D [N,3]  dL_dshs [N,M,3]  dL_dcolors [N,3]  dL_dopacity [N,1]
- *   dL_dscales [N,3]   dL_drotations [N,4]  dL_dcov3D [N,6]
+ *   dL_dscales [N,3]   dL_drotations [N,4]  dL_dcov3D [N,6]  dL_dshs_rest [N,M-1,3] (RAW_PARAMS only, else NULL)
  *   scratch: lg_backward_scratch_bytes(N, num_rendered)
  */
 int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii, const void* geom, const void* binning,
                 const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
                 float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                float* dL_dcov3D, void* scratch, void* stream);
+                float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream);
 
 /* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
  * prune pass to rebuild per-view scores from integer counts. */

@@ -18,7 +18,7 @@ LG_ERR_ALLOC = -3
 LG_ERR_PREFILTERED = -4
 
 WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
-FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE = 1, 2, 4
+FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS = 1, 2, 4, 8
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
@@ -35,7 +35,7 @@ class lg_view(C.Structure):
 class lg_gaussians(C.Structure):
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
-                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs_rest", C.c_void_p)]
 
 
 class lg_kernel_time(C.Structure):
@@ -81,7 +81,7 @@ def load():
     lib.lg_forward_count.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, ALLOC_FN, vp, C.c_int32, vp, vp, vp, vp, P(vp),
                                      P(C.c_int64), vp]
     lib.lg_backward.restype = C.c_int
-    lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 8 + [vp, vp]
+    lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 9 + [vp, vp]
     lib.lg_score_from_count.restype = C.c_int
     lib.lg_score_from_count.argtypes = [C.c_int32, vp, vp, vp, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]

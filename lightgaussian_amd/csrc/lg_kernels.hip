@@ -241,10 +241,17 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
     }
 }
 
+// RAW (section 8f row 1, "fused getters"): the inputs are GaussianModel's raw parameters -- log-scales, unnormalised
+// quaternions, opacity logits, and the SH coefficients as the two tensors _features_dc [N,1,3] / _features_rest
+// [N,M-1,3] -- and the activations (scene/gaussian_model.py:98-118) are evaluated here instead of by torch.
+__device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <bool RAW>
 __global__ void __launch_bounds__(LG_PP)
 lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
               const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-              const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+              const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+              const float* __restrict__ colors_precomp,
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
 {
@@ -272,18 +279,24 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
                 const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
                 float q[4] = { q4.x, q4.y, q4.z, q4.w };
+                if (RAW) {
+                    sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                    const float inv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); // F.normalize
+                    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+                }
                 lg_cov3d(sc, mod, q, cov);
             }
-            op = opacities[i];
+            op = RAW ? lg_sigmoid(opacities[i]) : opacities[i];
             vis = lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp);
         } else if (prefiltered) {
             g.counters[1] = 1u;
         }
     }
     const uint64_t vmask = __ballot(vis);
-    const int rowf = 3 * M;
-    if (shs && vmask) {
-        stage_sh_rows(shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
+    const bool split = RAW && shs_rest != nullptr;        // dc and rest are separate tensors
+    const int rowf = split ? 3 * (M - 1) : 3 * M;          // floats per LDS-staged row
+    if (shs && vmask && rowf > 0) {
+        stage_sh_rows(split ? shs_rest : shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -302,7 +315,11 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 float sh[LG_SH_MAXF];
                 const float* row = sh_rows + lane * rowf;
                 const int nact = (D + 1) * (D + 1) * 3;
-                if ((rowf & 3) == 0) {
+                if (split) {
+                    sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+#pragma unroll
+                    for (int k = 3; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k - 3] : 0.0f;
+                } else if ((rowf & 3) == 0) {
 #pragma unroll
                     for (int q = 0; q < LG_SH_MAXF / 4; q++) {
                         float4 v4 = make_float4(0, 0, 0, 0);
@@ -795,16 +812,18 @@ __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __r
 // ------------------------------------------------------------------------------------------------
 // K8 + K9 fused: per-Gaussian backward.  One wave per workgroup; SH rows in and dL/dSH rows out go
 // through LDS so that global traffic is coalesced 16-byte accesses.
+template <bool RAW>
 __global__ void __launch_bounds__(LG_PP)
 lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-                  const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                  const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                   const int32_t* __restrict__ radii, const float4* __restrict__ aux, const uint32_t* __restrict__ touched,
                   const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
-                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+                  float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                  float* __restrict__ dL_dscales, float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
 {
     __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
     const uint32_t lane = threadIdx.x;
@@ -816,11 +835,12 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
     const bool vis = (i < N) && radii[i] > 0;
     const uint64_t vmask = __ballot(vis);
-    const int rowf = 3 * M;
+    const bool split = RAW && shs_rest != nullptr;
+    const int rowf = split ? 3 * (M - 1) : 3 * M;
     const int rows = min(LG_PP, N - i0);
     const bool use_sh = (shs != nullptr) && (dL_dshs != nullptr);
-    if (use_sh && vmask) {
-        stage_sh_rows(shs, i0, rows, rowf, vmask, sh_rows, lane);
+    if (use_sh && vmask && rowf > 0) {
+        stage_sh_rows(split ? shs_rest : shs, i0, rows, rowf, vmask, sh_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -858,7 +878,11 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
             float sh[LG_SH_MAXF];
             const float* row = sh_rows + lane * rowf;
             const int nact = (D + 1) * (D + 1) * 3;
-            if ((rowf & 3) == 0) {
+            if (split) {
+                sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+#pragma unroll
+                for (int k = 3; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k - 3] : 0.0f;
+            } else if ((rowf & 3) == 0) {
 #pragma unroll
                 for (int q = 0; q < LG_SH_MAXF / 4; q++) {
                     float4 v4 = make_float4(0, 0, 0, 0);
@@ -878,14 +902,38 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
             float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
             const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
             float q[4] = { q4.x, q4.y, q4.z, q4.w };
+            float qn = 1.0f;
+            if (RAW) {
+                sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+                const float inv = 1.0f / qn;
+                q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+            }
             lg_backward_cov3d(sc, mod, q, go.cov3D, dsc, drot);
+            if (RAW) {
+                // exp: d/draw = d/ds * s ; normalize: d/dr = (g - q (q.g)) / |r|
+                dsc[0] *= sc[0]; dsc[1] *= sc[1]; dsc[2] *= sc[2];
+                const float qg = q[0] * drot[0] + q[1] * drot[1] + q[2] * drot[2] + q[3] * drot[3];
+                const float inv = 1.0f / qn;
+#pragma unroll
+                for (int k = 0; k < 4; k++) drot[k] = (drot[k] - q[k] * qg) * inv;
+            }
+        }
+        if (RAW) { // sigmoid: d/dlogit = d/dsigma * sigma (1 - sigma)
+            const float sg = lg_sigmoid(opacities[i]);
+            dop = dop * sg * (1.0f - sg);
         }
     }
     if (use_sh) {
         // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced
         __builtin_amdgcn_wave_barrier();
         float* row = sh_rows + lane * rowf;
-        if ((rowf & 3) == 0) {
+        if (split) {
+            if (i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
+#pragma unroll
+            for (int k = 3; k < LG_SH_MAXF; k++)
+                if (k - 3 < rowf) row[k - 3] = dsh[k];
+        } else if ((rowf & 3) == 0) {
 #pragma unroll
             for (int q = 0; q < LG_SH_MAXF / 4; q++)
                 if (q * 4 < rowf) reinterpret_cast<float4*>(row)[q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
@@ -897,14 +945,16 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float* dst = dL_dshs + (size_t)i0 * rowf;
+        float* dst = (split ? dL_dshs_rest : dL_dshs) + (size_t)i0 * rowf;
         const int nfl = rows * rowf;
-        if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-            const int nvec = nfl >> 2;
-            for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(sh_rows)[q];
-            for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
-        } else {
-            for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+        if (nfl > 0) {
+            if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+                const int nvec = nfl >> 2;
+                for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(sh_rows)[q];
+                for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+            } else {
+                for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+            }
         }
     }
     if (i >= N) return;
@@ -932,6 +982,11 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
     const bool sr = g->scales != nullptr && g->rotations != nullptr;
     if ((g->scales != nullptr) != (g->rotations != nullptr) || sr == (g->cov3D_precomp != nullptr))
         return fail(LG_ERR_INVALID_ARGUMENT, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (g->shs_rest && !(v->flags & LG_FLAG_RAW_PARAMS)) return fail(LG_ERR_INVALID_ARGUMENT, "shs_rest needs LG_FLAG_RAW_PARAMS");
+    if ((v->flags & LG_FLAG_RAW_PARAMS) && (g->cov3D_precomp || g->colors_precomp))
+        return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_RAW_PARAMS takes raw scales/rotations/opacities and SH tensors only");
+    if ((v->flags & LG_FLAG_RAW_PARAMS) && g->shs && g->M > 1 && !g->shs_rest)
+        return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_RAW_PARAMS with M > 1 needs shs (dc) and shs_rest");
     if (g->shs) {
         if (!(g->M == 1 || g->M == 4 || g->M == 9 || g->M == 16)) return fail(LG_ERR_INVALID_ARGUMENT, "M must be 1, 4, 9 or 16");
         if (v->sh_degree < 0 || v->sh_degree > 3 || (v->sh_degree + 1) * (v->sh_degree + 1) > g->M)
@@ -980,10 +1035,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
         {
             ProfScope ps(prof, "preprocess", stream);
-            lg_preprocess<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
-                                                                v->prefiltered, v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs,
-                                                                g->colors_precomp, g->opacities, g->scales, g->rotations,
-                                                                g->cov3D_precomp, geo, out_radii);
+#define LAUNCH_PP(RAWP)                                                                                                              \
+    lg_preprocess<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,           \
+                                                                      v->scale_modifier, v->prefiltered, v->viewmatrix, v->projmatrix, \
+                                                                      v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
+                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
+            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PP(true); else LAUNCH_PP(false);
+#undef LAUNCH_PP
         }
         KCHECK("lg_preprocess");
         lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.counters);
@@ -1094,10 +1152,11 @@ extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void
 extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
                            const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
                            float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                           float* dL_dcov3D, void* scratch, void* stream_p)
+                           float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p)
 {
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
+    if (g->shs_rest && !dL_dshs_rest) return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for shs_rest");
     if (!radii || !geom_p || !bin_p || !img_p || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacity || !scratch)
         return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
     if ((g->shs && !dL_dshs) || (g->colors_precomp && !dL_dcolors) || (g->scales && (!dL_dscales || !dL_drotations)) ||
@@ -1133,12 +1192,14 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     KCHECK("lg_blend_bwd");
     {
         ProfScope ps(prof, "preprocess_bwd", stream);
-        lg_preprocess_bwd<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier,
-                                                                v->viewmatrix, v->projmatrix, v->campos, g->means3D, g->shs, g->colors_precomp,
-                                                                g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched, geo.offsets,
-                                                                reinterpret_cast<const float4*>(acc),
-                                                                dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales,
-                                                                dL_drotations, dL_dcov3D);
+#define LAUNCH_PPB(RAWP)                                                                                                             \
+    lg_preprocess_bwd<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(                                                           \
+        N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
+        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched,  \
+        geo.offsets, reinterpret_cast<const float4*>(acc), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        dL_dscales, dL_drotations, dL_dcov3D)
+        if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
+#undef LAUNCH_PPB
     }
     KCHECK("lg_preprocess_bwd");
     return LG_OK;

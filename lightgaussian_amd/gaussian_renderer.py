@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 from .sh_utils import eval_sh
 
 
@@ -94,3 +94,19 @@ def count_render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mod
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "gaussians_count": gaussians_count, "important_score": important_score}
+
+
+def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    """render() with the getters fused into the kernels (opt-in extension -- the reference's
+    render() evaluates exp/sigmoid/normalize and cat(_features_dc, _features_rest) in torch on every call, which at
+    3M Gaussians costs as much HBM traffic as the whole rasterizer).  Reads GaussianModel's raw tensors
+    (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation: scene/gaussian_model.py:45-60) directly; same
+    result dict, gradients land on the raw parameters.  Falls back to render() for the Python-side alternates."""
+    if override_color is not None or pipe.convert_SHs_python or pipe.compute_cov3D_python:
+        return render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+    screenspace_points = _screenspace_points(pc)
+    rs = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False)
+    rendered_image, radii = rasterize_gaussians_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
+                                                    pc._scaling, pc._rotation, rs)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}

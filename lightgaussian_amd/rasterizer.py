@@ -67,7 +67,7 @@ def _prep(t, dev):
 class _Call:
     """Holds the tensors referenced by the C structs alive for the duration of a call."""
 
-    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact):
+    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact, sh_rest=None, raw=False):
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("lightgaussian_amd rasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
@@ -83,9 +83,10 @@ class _Call:
         self.vm = _prep(rs.viewmatrix, dev)
         self.pm = _prep(rs.projmatrix, dev)
         self.cp = _prep(rs.campos, dev)
+        self.sh_rest = _prep(sh_rest, dev)
         N = self.means3D.shape[0] if self.means3D is not None else 0
-        M = 0 if self.sh is None else int(self.sh.shape[1])
-        flags = 0
+        M = 0 if self.sh is None else int(self.sh.shape[1]) + (0 if sh_rest is None else int(sh_rest.shape[1]))
+        flags = _lib.FLAG_RAW_PARAMS if raw else 0
         if rs.debug:
             flags |= _lib.FLAG_DEBUG
         if _OPTIONS["fast_exp"] and not exact:
@@ -96,7 +97,7 @@ class _Call:
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
                                  int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags)
         self.g = _lib.lg_gaussians(N, M, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
-                                   _ptr(self.scales), _ptr(self.rots), _ptr(self.cov))
+                                   _ptr(self.scales), _ptr(self.rots), _ptr(self.cov), _ptr(self.sh_rest))
         self.N, self.M = N, M
 
 
@@ -183,12 +184,85 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
             rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
                                  C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
-                                 _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov),
+                                 _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov), None,
                                  _ptr(scratch), stream)
             _lib.check(rc)
         had_sh, had_col, had_sc, had_cov = ctx.had
         return (g_means3D, g_means2D, g_sh if had_sh else None, g_col if had_col else None, g_opac,
                 g_sc if had_sc else None, g_rot if had_sc else None, g_cov if had_cov else None, None)
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """SURVEY 8f row 1 ("fused getters"): rasterise straight from GaussianModel's RAW parameters.  The
+    activations of scene/gaussian_model.py:98-118 (exp / normalize / sigmoid) and the cat of
+    _features_dc/_features_rest run inside K1, their backward inside K9 (LG_FLAG_RAW_PARAMS)."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings):
+        lib = _lib.load()
+        rs = raster_settings
+        if rs.f_count:
+            raise Exception("raw-parameter rasterisation is a training path; use count_render for significance")
+        rest = features_rest if (features_rest is not None and features_rest.shape[1] > 0) else None
+        call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True)
+        dev, N = call.dev, call.N
+        H, W = int(rs.image_height), int(rs.image_width)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            u8 = dict(dtype=torch.uint8, device=dev)
+            geom = torch.empty(lib.lg_geom_bytes(N), **u8)
+            img = torch.empty(lib.lg_img_bytes(W, H), **u8)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((N,), dtype=torch.int32, device=dev)
+            holder = {}
+
+            def _alloc(_user, nbytes):
+                holder["t"] = torch.empty(max(int(nbytes), 1), **u8)
+                return holder["t"].data_ptr()
+
+            cb = _lib.ALLOC_FN(_alloc)
+            bin_ptr = C.c_void_p()
+            R = C.c_int64(0)
+            rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),
+                                C.byref(bin_ptr), C.byref(R), stream)
+            _lib.check(rc)
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(R.value)
+        ctx.has_rest = rest is not None
+        ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
+        ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, holder.get("t"), img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        lib = _lib.load()
+        rs = ctx.raster_settings
+        xyz, dc, rest, opac, scales, rots, radii, geom, binning, img = ctx.saved_tensors
+        call = _Call(rs, xyz, dc, None, opac, scales, rots, None, exact=False, sh_rest=rest, raw=True)
+        dev, N = call.dev, call.N
+        H, W = int(rs.image_height), int(rs.image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_color = torch.zeros((3, H, W), **f32) if grad_color is None else _prep(grad_color, dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            g_means2D = torch.empty((N, 3), **f32); g_xyz = torch.empty((N, 3), **f32); g_opac = torch.empty((N, 1), **f32)
+            g_dc = torch.empty((N, 1, 3), **f32)
+            g_rest = torch.empty((N, rest.shape[1], 3), **f32) if rest is not None else None
+            g_sc = torch.empty((N, 3), **f32); g_rot = torch.empty((N, 4), **f32)
+            scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
+            rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                 C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_xyz), _ptr(g_dc), None,
+                                 _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), None, _ptr(g_rest), _ptr(scratch), stream)
+            _lib.check(rc)
+        if g_rest is None and ctx.rest_shape is not None:
+            g_rest = torch.zeros(ctx.rest_shape, **f32)
+        return g_xyz, g_means2D, g_dc, g_rest, g_opac, g_sc, g_rot, None
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings):
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations,
+                                        raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -233,3 +233,35 @@ def test_sharded_prune_pass_collectives_on_rccl():
         dist.destroy_process_group()
     m = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, s1, 0.1))
     assert 0 < int(m.sum()) < 4000
+
+
+@pytest.mark.parametrize("deg", [3, 1, 0])
+def test_fused_getters_match_unfused_render(deg):
+    """render_fused (activations + cat inside the kernels) vs render() on the same raw parameters:
+    image within 1e-5, gradients w.r.t. the RAW parameters within 1e-4 (different exp/sigmoid implementations only)."""
+    import gpu_common
+    from lightgaussian_amd.gaussian_renderer import render, render_fused
+    dev = torch.device("cuda:0")
+    W, H, N = 200, 120, 5000
+    cam = syn.orbit_camera(1, 5, W, H, radius=5.0).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    pipe = syn.PipelineParams()
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = []
+    for fn in (render, render_fused):
+        g = syn.make_gaussians(N, sh_degree=deg, seed=4, log_scale_mean=math.log(0.04), opacity_mean=0.5, extent=(2, 1.2, 2)).to(dev)
+        g.requires_grad_(True)
+        pkg = fn(cam, g, pipe, bg)
+        (pkg["render"] * gimg).sum().backward()
+        outs.append((pkg["render"].detach().cpu().numpy(), pkg["radii"].cpu().numpy(), pkg["viewspace_points"].grad.cpu().numpy(),
+                     [t.grad.cpu().numpy() if t.grad is not None else None
+                      for t in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)]))
+    (ia, ra, va, ga), (ib, rb, vb, gb) = outs
+    assert np.array_equal(ra, rb)
+    assert gpu_common.rel_err(ib, ia) <= 1e-5
+    assert gpu_common.rel_err(vb, va) <= TOL
+    for name, x, y in zip(("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"), ga, gb):
+        if x is None or x.size == 0:
+            continue
+        assert y is not None, name
+        assert gpu_common.rel_err(y, x) <= TOL, f"{name}: {gpu_common.rel_err(y, x):.3e}"
