@@ -219,6 +219,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 // culled Gaussians -- instead of 48 strided dword loads per lane.
 #define LG_PP 64
 #define LG_SH_MAXF 48 // floats per SH row at M = 16
+#define LG_COOP_ROWS 48u // K9: splats with more tile instances than this are gathered by the whole wave
 
 // cooperative copy of the wave's SH rows into LDS (flat layout, row stride = rowf floats)
 __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int i0, int rows, int rowf, uint64_t need_mask,
@@ -651,18 +652,22 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
     const float op = b.y;
     const float alpha = fminf(LG_ALPHA_MAX, op * G);
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
-    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (0*c + 1*a = a)
+    // and dch = 0, so four of the seven selects of a naive branch-free form disappear (v_cndmask / v_cmp / v_min cost
+    // ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).  T keeps its select: rcp(1.0) need not be exactly 1.
+    const float am = ok ? alpha : 0.0f;
+    const float om = 1.0f - am;
+    const float inv = __builtin_amdgcn_rcpf(om);
     const float Tn = T * inv;
     const float c0 = b.z, c1 = b.w, c2 = c.x;
     // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence)
+    const float dch = am * Tn;
     float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * Tn - (T_final * inv) * bg_dot;
     dL_dalpha = ok ? dL_dalpha : 0.0f;
-    const float dch = ok ? alpha * Tn : 0.0f;
-    const float om = 1.0f - alpha;
     T = ok ? Tn : T;
-    a0 = ok ? alpha * c0 + om * a0 : a0;
-    a1 = ok ? alpha * c1 + om * a1 : a1;
-    a2 = ok ? alpha * c2 + om * a2 : a2;
+    a0 = am * c0 + om * a0;
+    a1 = am * c1 + om * a1;
+    a2 = am * c2 + om * a2;
     const float dL_dG = op * dL_dalpha;
     const float gdx = G * dx, gdy = G * dy;
     // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
@@ -797,6 +802,211 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K7 (training variant): backward blend with the pixel reduction on the f32 MFMA pipe.
+//
+// For one (Gaussian j, 8x8 sub-block) the nine gradient sums are contractions over the 64 pixels:
+//   colour     p6..8 = sum_px DCH(px,j) * g_c(px)                          DCH = alpha*T, g = dL/dpixel
+//   geometry   p0..5 = linear combinations of the six moments sum_px W(px,j) * {1,u,v,u^2,uv,v^2}
+//              with W = dL/dG * G and (u,v) the pixel offset from the sub-block centre (|u|,|v| <= 3.5);
+//              dx = X - u, dy = Y - v with (X,Y) = Gaussian centre relative to that centre
+// i.e. two small GEMMs  [16 x 64] . [64 x 16 entries].  The VALU stream only produces W and DCH per pixel
+// (no nine partial products, no cross-lane reduction); v_mfma_f32_16x16x4_f32 (exact f32, separate pipe)
+// does the sums for 16 pending entries at a time.  Order of evaluation inside a sub-block is still back to
+// front, and sub-blocks are independent pixel sets, so the batch is walked once per sub-block.
+typedef float lg_f4v __attribute__((ext_vector_type(4)));
+#define LG_MF_STRIDE 66 // floats per pending-entry row in LDS: (66*j + 4t + k) is conflict-free for the operand reads
+
+__device__ __forceinline__ bool bwd_pair_wd(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
+                                            float T_final, float g0, float g1, float g2, float bg_dot, float& a0, float& a1, float& a2,
+                                            float& Wout, float& Dout)
+{
+#pragma clang fp contract(fast)
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
+    const float G = __expf(fminf(power, 0.0f));
+    const float op = b.y;
+    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    const float Tn = T * inv;
+    const float c0 = b.z, c1 = b.w, c2 = c.x;
+    float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * Tn - (T_final * inv) * bg_dot;
+    const float om = 1.0f - alpha;
+    T = ok ? Tn : T;
+    a0 = ok ? alpha * c0 + om * a0 : a0;
+    a1 = ok ? alpha * c1 + om * a1 : a1;
+    a2 = ok ? alpha * c2 + om * a2 : a2;
+    Wout = ok ? (op * dL_dalpha) * G : 0.0f;
+    Dout = ok ? alpha * Tn : 0.0f;
+    return ok;
+}
+
+__global__ void __launch_bounds__(64)
+lg_blend_bwd_mfma(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
+                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_sorted, const float4* __restrict__ rec,
+                  const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                  const float* __restrict__ dL_dpix, float* __restrict__ part)
+{
+    __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
+    __shared__ float stage[LG_Q * 9];
+    __shared__ float wbuf[16 * LG_MF_STRIDE], dbuf[16 * LG_MF_STRIDE];
+    __shared__ float gT[4 * 3 * 64];
+    const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
+    if (tile >= ntiles) return;
+    const uint32_t lane = threadIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)H * W;
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+
+    float T[4], Tfin[4], g0[4], g1[4], g2[4], bgd[4], a0[4], a1[4], a2[4];
+    uint32_t last[4];
+    uint32_t wmax = 0;
+    const float lxf = (float)(lane & 7), lyf = (float)(lane >> 3);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int pxi = tx * LG_TILE + (s & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (s >> 1) * 8 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const size_t pid = (size_t)pyi * W + pxi;
+        Tfin[s] = inside ? final_T[pid] : 0.0f;
+        T[s] = Tfin[s];
+        last[s] = inside ? n_contrib[pid] : 0u;
+        g0[s] = inside ? dL_dpix[pid] : 0.0f;
+        g1[s] = inside ? dL_dpix[HW + pid] : 0.0f;
+        g2[s] = inside ? dL_dpix[2 * HW + pid] : 0.0f;
+        bgd[s] = bgr * g0[s] + bgg * g1[s] + bgb * g2[s];
+        a0[s] = a1[s] = a2[s] = 0.0f;
+        wmax = max(wmax, last[s]);
+        gT[(s * 3 + 0) * 64 + lane] = g0[s]; gT[(s * 3 + 1) * 64 + lane] = g1[s]; gT[(s * 3 + 2) * 64 + lane] = g2[s];
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    const uint32_t n_list = range.y - range.x;
+    if (n_list == 0) return;
+    if (wmax > n_list) wmax = n_list;
+    const float tbx = (float)(tx * LG_TILE), tby = (float)(ty * LG_TILE);
+    float4* rows = reinterpret_cast<float4*>(part);
+
+    // MFMA operand geometry of this lane: output row i = lane % 16, k = lane / 16 (pixel 4t + k of K-step t), entry column j = lane % 16
+    const uint32_t mi = lane & 15u, mk = lane >> 4;
+    // A operand of the moment chain: basis_i(u, v) of pixel 4t + k, i = 0..5 -> {1, u, v, u^2, uv, v^2}, else 0 (same for all sub-blocks)
+    float Aw[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const uint32_t p = 4u * (uint32_t)t + mk;
+        const float u = (float)(p & 7u) - 3.5f, v = (float)(p >> 3) - 3.5f;
+        float bval = 0.0f;
+        bval = mi == 0u ? 1.0f : bval; bval = mi == 1u ? u : bval; bval = mi == 2u ? v : bval;
+        bval = mi == 3u ? u * u : bval; bval = mi == 4u ? u * v : bval; bval = mi == 5u ? v * v : bval;
+        Aw[t] = bval;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for (int k = (int)((n_list - 1) / LG_Q); k >= 0; k--) {
+        const uint32_t base = range.x + (uint32_t)k * LG_Q;
+        const uint32_t nbt = min((uint32_t)LG_Q, n_list - (uint32_t)k * LG_Q);
+        const uint32_t nb = wmax > (uint32_t)k * LG_Q ? min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q) : 0u;
+        uint64_t hitmask = 0;
+        if (nb > 0) {
+            if (lane < nb) {
+                const uint32_t id = point_list[base + lane];
+                const float4 r0 = rec[3 * (size_t)id], r1 = rec[3 * (size_t)id + 1], r2 = rec[3 * (size_t)id + 2];
+                uint32_t m = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
+                    const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
+                    m |= (hit ? 1u : 0u) << s;
+                }
+                q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
+            }
+#pragma unroll
+            for (int c9 = 0; c9 < 9; c9++) stage[lane * 9 + c9] = 0.0f;
+            __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                // A operand of the colour chain for this sub-block: g_i(pixel 4t + k), i < 3
+                float Ag[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) Ag[t] = mi < 3u ? gT[(s * 3 + (int)mi) * 64 + 4 * t + (int)mk] : 0.0f;
+                const float pxf = tbx + (float)((s & 1) * 8) + lxf, pyf = tby + (float)((s >> 1) * 8) + lyf;
+                const float cxs = tbx + (float)((s & 1) * 8) + 3.5f, cys = tby + (float)((s >> 1) * 8) + 3.5f;
+                uint32_t cnt = 0;        // pending entries of this sub-block (uniform)
+                uint32_t myentry = 0;    // lane e < cnt: batch index of pending entry e
+                int j = (int)nb - 1;
+                while (true) {
+                    // ---- evaluate entries back to front until 16 are pending or the batch is exhausted ----
+                    for (; j >= 0 && cnt < 16u; j--) {
+                        const float4 c = q2[j];
+                        const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+                        if (!(m & (1u << s))) continue;
+                        const float4 a = q0[j], b = q1[j];
+                        const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
+                        float Wv, Dv;
+                        const bool ok = bwd_pair_wd(a, b, c, rel <= last[s], pxf, pyf, T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s],
+                                                    a2[s], Wv, Dv);
+                        if (__ballot(ok) == 0) continue;
+                        wbuf[cnt * LG_MF_STRIDE + lane] = Wv;
+                        dbuf[cnt * LG_MF_STRIDE + lane] = Dv;
+                        myentry = (lane == cnt) ? (uint32_t)j : myentry;
+                        hitmask |= 1ull << j;
+                        cnt++;
+                    }
+                    if (cnt == 0) break;
+                    // ---- flush: sums over the 64 pixels for the pending entries on the matrix pipe ----
+                    __builtin_amdgcn_wave_barrier();
+                    lg_f4v accw = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const bool colok = mi < cnt;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const float bw = colok ? wbuf[mi * LG_MF_STRIDE + 4 * t + mk] : 0.0f;
+                        const float bd = colok ? dbuf[mi * LG_MF_STRIDE + 4 * t + mk] : 0.0f;
+                        accw = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[t], bw, accw, 0, 0, 0);
+                        accd = __builtin_amdgcn_mfma_f32_16x16x4f32(Ag[t], bd, accd, 0, 0, 0);
+                    }
+                    // lane l holds rows 4*(l/16)..+3 of column l%16: moments {1,u,v,uu} in lanes 0-15, {uv,vv} in lanes 16-31
+                    const float Suv = __shfl(accw[0], (int)(lane + 16u) & 63), Svv = __shfl(accw[1], (int)(lane + 16u) & 63);
+                    if (lane < cnt) {
+                        const float4 ea = q0[myentry], eb = q1[myentry];
+                        const float X = ea.x - cxs, Y = ea.y - cys;
+                        const float S0 = accw[0], Su = accw[1], Sv = accw[2], Suu = accw[3];
+                        const float Wdx = X * S0 - Su, Wdy = Y * S0 - Sv;
+                        const float Wdxx = X * X * S0 - 2.0f * X * Su + Suu;
+                        const float Wdxy = X * Y * S0 - X * Sv - Y * Su + Suv;
+                        const float Wdyy = Y * Y * S0 - 2.0f * Y * Sv + Svv;
+                        float* dst = stage + myentry * 9;
+                        dst[0] += 2.0f * ea.z * Wdx + ea.w * Wdy;
+                        dst[1] += 2.0f * eb.x * Wdy + ea.w * Wdx;
+                        dst[2] += -0.5f * Wdxx;
+                        dst[3] += -Wdxy;
+                        dst[4] += -0.5f * Wdyy;
+                        dst[5] += (eb.y != 0.0f) ? S0 / eb.y : 0.0f;
+                        dst[6] += accd[0]; dst[7] += accd[1]; dst[8] += accd[2];
+                    }
+                    cnt = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (j < 0) break;
+                }
+            }
+        }
+        if (lane < nbt) {
+            float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0;
+            if ((hitmask >> lane) & 1ull) {
+                const float* src = stage + lane * 9;
+                o0 = make_float4(src[0], src[1], src[2], src[3]);
+                o1 = make_float4(src[4], src[5], src[6], src[7]);
+                o2 = make_float4(src[8], 0.0f, 0.0f, 0.0f);
+            }
+            float4* dst = rows + 3 * (size_t)slot_sorted[base + lane];
+            dst[0] = o0; dst[1] = o1; dst[2] = o2;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // diagnostics: wave_reduce9_to_lds on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
 __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
 {
@@ -845,18 +1055,45 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // Screen-filling splats own thousands of gradient rows; a single lane walking them would stall its wave for
+    // milliseconds.  Such lanes are served one at a time by the whole wave: 64 rows per step, then a wave reduction.
+    const uint32_t my_t = vis ? touched[i] : 0u;
+    const uint32_t my_u0 = vis ? offsets[i] - my_t : 0u;
+    float coop[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        uint64_t big = __ballot(my_t > LG_COOP_ROWS);
+        while (big) {
+            const int src = (int)__builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, src);
+            const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)my_u0, src);
+            float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t u = u0 + lane; u < u0 + t; u += LG_PP) {
+                const float4* rp = part + 3 * (size_t)u;
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                acc9[0] += v0.x; acc9[1] += v0.y; acc9[2] += v0.z; acc9[3] += v0.w; acc9[4] += v1.x; acc9[5] += v1.y; acc9[6] += v1.z;
+                acc9[7] += v1.w; acc9[8] += v2.x;
+            }
+#pragma unroll
+            for (int k9 = 0; k9 < 9; k9++) {
+                const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(acc9[k9])), 63));
+                if ((int)lane == src) coop[k9] = tot;
+            }
+        }
+    }
     float m2[3] = {0, 0, 0}, m3[3] = {0, 0, 0}, dop = 0.0f, dsc[3] = {0, 0, 0}, drot[4] = {0, 0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     float dcol[3] = {0, 0, 0};
     float dsh[LG_SH_MAXF];
 #pragma unroll
     for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = 0.0f;
     if (vis) {
-        // gather this Gaussian's gradient rows (one per tile instance) in slot order: deterministic, no atomics
-        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        {
-            const uint32_t t = touched[i];
-            const uint32_t u0 = offsets[i] - t;
-            for (uint32_t u = u0; u < u0 + t; u++) {
+        // gather this Gaussian's gradient rows (one per tile instance) in slot order: deterministic, no atomics.
+        // Splats with more than LG_COOP_ROWS instances were summed cooperatively by the whole wave (below).
+        float a[9];
+#pragma unroll
+        for (int k9 = 0; k9 < 9; k9++) a[k9] = coop[k9];
+        if (my_t <= LG_COOP_ROWS) {
+            for (uint32_t u = my_u0; u < my_u0 + my_t; u++) {
                 const float4* rp = part + 3 * (size_t)u;
                 const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
                 a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w; a[8] += v2.x;
@@ -1182,6 +1419,9 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
         else if (fast && abl == 2) LAUNCH_BWD(false, 2);
         else if (fast && abl == 3) LAUNCH_BWD(false, 3);
         else if (fast && abl == 4) LAUNCH_BWD(false, 4);
+        else if (fast && getenv("LG_BWD_MFMA") != nullptr) // experiment, off by default: correct but 1.8x slower
+            lg_blend_bwd_mfma<<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec,
+                                                            v->bg, img.final_T, img.n_contrib, dL_dcolor, acc);
         else if (fast)
             lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, acc);

@@ -26,6 +26,7 @@ CASES = [
     dict(N=2000, W=161, H=83, seed=4, scale=0.02, opm=-3.0, ext=(3, 2, 3), deg=1),            # ragged image size
     dict(N=1500, W=96, H=64, seed=5, scale=0.03, opm=0.0, ext=(2, 1, 2), deg=0, precolor=True),
     dict(N=1500, W=96, H=64, seed=6, scale=0.03, opm=0.0, ext=(2, 1, 2), deg=3, precov=True),
+    dict(N=300, W=320, H=240, seed=7, scale=0.6, opm=-1.5, ext=(2, 1, 2), deg=3),            # screen-filling splats: >48 tile instances each (cooperative row gather in K9)
 ]
 
 
