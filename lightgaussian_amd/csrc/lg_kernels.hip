@@ -449,6 +449,31 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad8)
 
 #define LG_Q 64 // LDS queue depth per wave = one batch
 
+// Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
+// every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
+template <bool EXACT>
+__device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
+                                         float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out)
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    const float pe = fminf(power, 0.0f);
+    const float ex = EXACT ? lg_exp(pe) : __expf(pe);
+    const float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    const float test_T = T * (1.0f - alpha);
+    const bool sat = ok && (test_T < LG_T_MIN);
+    const bool contrib = ok && !sat;
+    const float w = alpha * T;
+    const float n0 = fmaf(b.z, w, C0), n1 = fmaf(b.w, w, C1), n2 = fmaf(c.x, w, C2);
+    C0 = contrib ? n0 : C0; C1 = contrib ? n1 : C1; C2 = contrib ? n2 : C2;
+    T = contrib ? test_T : T;
+    last = contrib ? rel : last;
+    done = done || sat;
+    alpha_out = alpha;
+    return contrib;
+}
+
 // K6 / K6c: forward blend
 template <bool COUNT, bool FSCORE, bool EXACT>
 __global__ void __launch_bounds__(256)
@@ -500,13 +525,8 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __r
             const uint32_t src = (uint32_t)__builtin_ctzll(mask);
             mask &= mask - 1;
             const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
-            int res = 0;
             float alpha = 0.0f, Tprev = T;
-            if (!done) {
-                res = lg_blend_pair<EXACT>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, pxf, pyf, T, C0, C1, C2, alpha);
-                if (res == 2) done = true;
-                if (res == 1) last = rel + src;
-            }
+            const int res = fwd_pair<EXACT>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha) ? 1 : 0;
             if (COUNT) {
                 const uint64_t cm = __ballot(res == 1);
                 if (lane == j) mycnt = (int)__popcll(cm);
