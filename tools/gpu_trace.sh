@@ -13,7 +13,7 @@ import csv, collections
 rows = list(csv.DictReader(open('gpurun_out/trace_$MODE/t_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last 10 steps worth: find the periodic structure by the preprocess kernel
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('lg_preprocess(')]
+idx = [i for i, r in enumerate(rows) if ('lg_preprocess<' in r['Kernel_Name'] or r['Kernel_Name'].startswith('lg_preprocess('))]
 print('kernels', len(rows), 'preprocess launches', len(idx))
 lo, hi = idx[-11], idx[-1]
 seg = rows[lo:hi]
