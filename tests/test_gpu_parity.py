@@ -266,3 +266,54 @@ def test_fused_getters_match_unfused_render(deg):
             continue
         assert y is not None, name
         assert gpu_common.rel_err(y, x) <= TOL, f"{name}: {gpu_common.rel_err(y, x):.3e}"
+
+
+def test_weight_policies_alpha_and_alpha_t():
+    """The float per-hit weights (ALPHA, ALPHA_T) are order-dependent sums even in the reference; tolerance 1e-4.
+    ONE gives score == count exactly."""
+    import gpu_common
+    from lightgaussian_amd import _lib, rasterizer
+    kw = _scene(CASES[1])
+    try:
+        for pol, opol in ((_lib.WEIGHT_ONE, oracle.W_ONE), (_lib.WEIGHT_ALPHA, oracle.W_ALPHA), (_lib.WEIGHT_ALPHA_T, oracle.W_ALPHA_T)):
+            rasterizer.set_option("weight_policy", pol)
+            out = gpu_common.hip_forward_backward(kw, count=True)
+            ref = oracle.forward(count=True, weight_policy=opol, **_np(kw))
+            assert np.array_equal(out["count"], ref.count)
+            if pol == _lib.WEIGHT_ONE:
+                assert np.array_equal(out["score"], ref.count.astype(np.float32))
+            else:
+                assert gpu_common.rel_err(out["score"], ref.score) <= TOL
+    finally:
+        rasterizer.set_option("weight_policy", _lib.WEIGHT_OPACITY)
+
+
+def test_debug_flag_prefiltered_error_and_stale_count_api():
+    import gpu_common
+    from lightgaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    kw = _scene(CASES[4])
+    a = gpu_common.hip_forward_backward(kw, count=True)
+    b = gpu_common.hip_forward_backward(kw, count=True, debug=True)     # debug: sync + check after every kernel
+    assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["color"], b["color"])
+    dev = torch.device("cuda:0")
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    N = t["means3D"].shape[0]
+
+    def settings(**over):
+        base = dict(image_height=t["H"], image_width=t["W"], tanfovx=t["tanfovx"], tanfovy=t["tanfovy"], bg=t["bg"], scale_modifier=1.0,
+                    viewmatrix=t["viewmatrix"], projmatrix=t["projmatrix"], sh_degree=t["sh_degree"], campos=t["campos"],
+                    prefiltered=False, debug=False, f_count=False)
+        base.update(over)
+        return GaussianRasterizationSettings(**base)
+    args = dict(means3D=t["means3D"], means2D=torch.zeros(N, 3, device=dev), opacities=t["opacities"], colors_precomp=t["colors_precomp"],
+                scales=t["scales"], rotations=t["rotations"])
+    # stale API of gaussian_renderer/gaussian_count.py:69,112
+    cnt, score, color, radii = GaussianRasterizer(settings(), f_count=True).forward_counter(**args)
+    assert np.array_equal(cnt.cpu().numpy(), a["count"]) and np.array_equal(score.cpu().numpy(), a["score"])
+    # prefiltered=True promises that nothing fails the frustum test: a Gaussian behind the camera is an error
+    bad = dict(args); bad["means3D"] = t["means3D"].clone(); bad["means3D"][0] = t["campos"] - 10.0 * (t["means3D"].mean(0) - t["campos"])
+    with pytest.raises(RuntimeError, match="filtered"):
+        GaussianRasterizer(settings(prefiltered=True))(**bad)
+    # markVisible: frustum (near plane) test only
+    vis = GaussianRasterizer(settings()).markVisible(bad["means3D"])
+    assert not bool(vis[0]) and bool(vis[1:].all())
