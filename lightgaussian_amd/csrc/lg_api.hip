@@ -1,0 +1,308 @@
+// lg_api.hip -- C ABI (include/lightgaussian.h) of the gfx950 (CDNA4, wave64) LightGaussian rasterizer.
+// The single translation unit of liblightgaussian_hip.so; the kernels live in the headers it includes:
+//   lg_math.h        scalar float arithmetic shared with the CPU test harness (canonical operation order)
+//   lg_host.h        error strings, optional hipEvent profiler, scratch carving (GeomView / ImgView / BinView)
+//   lg_wave.h        wave64 primitives (DPP / permlane reductions)
+//   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
+//   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_finalize_bins   (per instance; K2/K4 = rocPRIM scan / radix sort)
+//   lg_blend.h       K6 lg_blend_fwd<COUNT,FSCORE,EXACT>, lg_score_kernel, K7 lg_blend_bwd<EXACT>   (per tile, VALU-bound)
+//
+// Pipeline of one view:
+//   K1 project + EWA + SH->RGB + exact footprint culling  ->  K2 scan of instance counts, blocking read of R
+//   K3 packed keys tile|depth|id  ->  K4 stable keys-only radix sort  ->  K5 tile ranges, ids, gradient-row slots
+//   K6 front-to-back blend (4 autonomous waves per 16x16 tile, LDS queue, select-based pair step, ballot early exit)
+//   K7 back-to-front replay (1 wave per tile, 4 px/lane, packed permlane reduction, one 48-B gradient row per instance)
+//   K9 per-Gaussian gather of its contiguous rows + cov2D/cov3D/projection/SH backward
+// Written for wave64; no CUDA compatibility paths.
+#include "lg_host.h"
+#include "lg_wave.h"
+#include "lg_preprocess.h"
+#include "lg_binning.h"
+#include "lg_blend.h"
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static int check_args(const lg_view* v, const lg_gaussians* g)
+{
+    if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
+    if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (g->N == 0) return LG_OK; // nothing to validate against: empty tensors carry no pointers
+    if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
+        return fail(LG_ERR_INVALID_ARGUMENT, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool sr = g->scales != nullptr && g->rotations != nullptr;
+    if ((g->scales != nullptr) != (g->rotations != nullptr) || sr == (g->cov3D_precomp != nullptr))
+        return fail(LG_ERR_INVALID_ARGUMENT, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (g->shs_rest && !(v->flags & LG_FLAG_RAW_PARAMS)) return fail(LG_ERR_INVALID_ARGUMENT, "shs_rest needs LG_FLAG_RAW_PARAMS");
+    if ((v->flags & LG_FLAG_RAW_PARAMS) && (g->cov3D_precomp || g->colors_precomp))
+        return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_RAW_PARAMS takes raw scales/rotations/opacities and SH tensors only");
+    if ((v->flags & LG_FLAG_RAW_PARAMS) && g->shs && g->M > 1 && !g->shs_rest)
+        return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_RAW_PARAMS with M > 1 needs shs (dc) and shs_rest");
+    if (g->shs) {
+        if (!(g->M == 1 || g->M == 4 || g->M == 9 || g->M == 16)) return fail(LG_ERR_INVALID_ARGUMENT, "M must be 1, 4, 9 or 16");
+        if (v->sh_degree < 0 || v->sh_degree > 3 || (v->sh_degree + 1) * (v->sh_degree + 1) > g->M)
+            return fail(LG_ERR_INVALID_ARGUMENT, "sh_degree needs (D+1)^2 <= M, D <= 3");
+    }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos || !g->means3D || !g->opacities)
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing required pointer");
+    const int gx = (v->image_width + LG_TILE - 1) / LG_TILE, gy = (v->image_height + LG_TILE - 1) / LG_TILE;
+    if (gx >= 65536 || gy >= 65536) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    return LG_OK;
+}
+
+#define KCHECK(name)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) return fail(LG_ERR_DEVICE, name " launch", _e);                \
+        if (debug) {                                                                         \
+            _e = hipStreamSynchronize(stream);                                               \
+            if (_e != hipSuccess) return fail(LG_ERR_DEVICE, name " execution", _e);         \
+        }                                                                                    \
+    } while (0)
+
+static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, void* img_p, lg_alloc_fn alloc, void* alloc_user,
+                        int weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
+                        void** binning_out, int64_t* num_rendered, void* stream_p)
+{
+    int rc = check_args(v, g);
+    if (rc != LG_OK) return rc;
+    if (!geom_p || !img_p || !out_color || (!out_radii && g->N > 0) || !alloc) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    const bool count = out_count != nullptr;
+    if (count && !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count needs score");
+    if (count && (weight_policy < 0 || weight_policy > 3)) return fail(LG_ERR_INVALID_ARGUMENT, "bad weight policy");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
+    const int N = g->N, W = v->image_width, H = v->image_height;
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
+    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    GeomView geo = carve_geom(geom_p, N);
+    ImgView img = carve_img(img_p, W, H);
+    const size_t HW = (size_t)W * H;
+
+    if (binning_out) *binning_out = nullptr;
+    if (num_rendered) *num_rendered = 0;
+    uint32_t h_counters[3] = {0, 0, 0}, h_R = 0;
+    if (N > 0) {
+        HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
+        {
+            ProfScope ps(prof, "preprocess", stream);
+#define LAUNCH_PP(RAWP)                                                                                                              \
+    lg_preprocess<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,           \
+                                                                      v->scale_modifier, v->prefiltered, v->viewmatrix, v->projmatrix, \
+                                                                      v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
+                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
+            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PP(true); else LAUNCH_PP(false);
+#undef LAUNCH_PP
+        }
+        KCHECK("lg_preprocess");
+        lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.counters);
+        KCHECK("lg_reduce_dmax");
+        {
+            ProfScope ps(prof, "scan", stream);
+            size_t tb = geo.scan_temp_bytes;
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(geo.scan_temp, tb, geo.touched, geo.offsets, N, stream));
+        }
+        HIP_TRY(hipMemcpyAsync(&h_R, geo.offsets + (N - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_counters, geo.counters, 12, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
+    const int64_t R = h_R;
+    g_stats.num_rendered = R;
+    g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
+    if (num_rendered) *num_rendered = R;
+
+    // key format: packed single-u64 keys when tile | depth | id fit 64 bits (they do for every BASELINE config)
+    const int tile_bits = bits_for((uint32_t)ntiles), gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
+    const uint32_t dspan = h_counters[2] > LG_DEPTH_BIAS ? h_counters[2] - LG_DEPTH_BIAS : 0u;
+    const int depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
+    const bool packed = (tile_bits + depth_bits + gid_bits <= 64) && (getenv("LG_FORCE_PAIR_SORT") == nullptr);
+
+    void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, packed).total);
+    if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
+    if (binning_out) *binning_out = bin_p;
+    BinView bin = carve_bin(bin_p, R, W, H, packed);
+    HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
+    const uint32_t* point_list = bin.point_list;
+    if (R > 0) {
+        {
+            ProfScope ps(prof, "duplicate", stream);
+            if (packed)
+                lg_duplicate<true><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, depth_bits, gid_bits, geo.touched, geo.offsets, geo.tinfo,
+                                                                        bin.keys_in, nullptr, nullptr);
+            else
+                lg_duplicate<false><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, 0, 0, geo.touched, geo.offsets, geo.tinfo, bin.keys_in,
+                                                                         bin.slot_in, bin.gid_slot);
+        }
+        KCHECK("lg_duplicate");
+        {
+            ProfScope ps(prof, "sort", stream);
+            size_t tb = bin.sort_temp_bytes;
+            if (packed)
+                HIP_TRY(hipcub::DeviceRadixSort::SortKeys(bin.sort_temp, tb, bin.keys_in, bin.keys_out, (int)R, gid_bits,
+                                                          gid_bits + depth_bits + tile_bits, stream));
+            else
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
+                                                           32 + tile_bits, stream));
+        }
+        {
+            ProfScope ps(prof, "finalize_bins", stream);
+            if (packed)
+                lg_finalize_bins<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, depth_bits, gid_bits, bin.keys_out,
+                                                                                        geo.tinfo, nullptr, nullptr, bin.point_list,
+                                                                                        bin.slot_out, bin.ranges);
+            else
+                lg_finalize_bins<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, 0, 0, bin.keys_out, geo.tinfo,
+                                                                                         bin.slot_out, bin.gid_slot, bin.point_list,
+                                                                                         bin.slot_out, bin.ranges);
+        }
+        KCHECK("lg_finalize_bins");
+    }
+    if (count && N > 0) {
+        HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
+        HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
+    }
+    {
+        ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
+        dim3 grid(ntiles_pad8), block(256);
+#define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, point_list, geo.rec, v->bg,     \
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
+        const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
+        if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
+        else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
+        else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
+#undef LAUNCH_FWD
+    }
+    KCHECK("lg_blend_fwd");
+    (void)HW;
+    if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
+        ProfScope ps(prof, "score", stream);
+        lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
+        KCHECK("lg_score_kernel");
+    }
+    return LG_OK;
+}
+
+extern "C" int lg_forward(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+                          float* out_color, int32_t* out_radii, void** binning_out, int64_t* num_rendered, void* stream)
+{
+    return forward_impl(view, g, geom, img, alloc, alloc_user, LG_WEIGHT_OPACITY, out_color, out_radii, nullptr, nullptr, binning_out,
+                        num_rendered, stream);
+}
+
+extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
+                                int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
+                                void** binning_out, int64_t* num_rendered, void* stream)
+{
+    if (g && g->N > 0 && (!out_count || !out_score)) return fail(LG_ERR_INVALID_ARGUMENT, "count/score outputs required");
+    return forward_impl(view, g, geom, img, alloc, alloc_user, weight_policy, out_color, out_radii, out_count, out_score, binning_out,
+                        num_rendered, stream);
+}
+
+extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
+                           const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                           float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                           float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p)
+{
+    int rc = check_args(v, g);
+    if (rc != LG_OK) return rc;
+    if (g->shs_rest && !dL_dshs_rest) return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for shs_rest");
+    if (!radii || !geom_p || !bin_p || !img_p || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacity || !scratch)
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    if ((g->shs && !dL_dshs) || (g->colors_precomp && !dL_dcolors) || (g->scales && (!dL_dscales || !dL_drotations)) ||
+        (g->cov3D_precomp && !dL_dcov3D))
+        return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for a provided input");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
+    const int N = g->N, W = v->image_width, H = v->image_height;
+    if (N == 0) return LG_OK;
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
+    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
+    ImgView img = carve_img(const_cast<void*>(img_p), W, H);
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
+    float* acc = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
+    if (R > 0) {
+        ProfScope ps(prof, "blend_bwd", stream);
+        if (fast)
+            lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+                                                                 img.final_T, img.n_contrib, dL_dcolor, acc);
+        else
+            lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+                                                                img.final_T, img.n_contrib, dL_dcolor, acc);
+    }
+    KCHECK("lg_blend_bwd");
+    {
+        ProfScope ps(prof, "preprocess_bwd", stream);
+#define LAUNCH_PPB(RAWP)                                                                                                             \
+    lg_preprocess_bwd<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(                                                           \
+        N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
+        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched,  \
+        geo.offsets, reinterpret_cast<const float4*>(acc), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        dL_dscales, dL_drotations, dL_dcov3D)
+        if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
+#undef LAUNCH_PPB
+    }
+    KCHECK("lg_preprocess_bwd");
+    return LG_OK;
+}
+
+extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream_p)
+{
+    if (N < 0 || (N > 0 && (!count || !score))) return fail(LG_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (N == 0) return LG_OK;
+    hipStream_t stream = (hipStream_t)stream_p;
+    lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_score_kernel launch", e);
+    return LG_OK;
+}
+
+extern "C" int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream_p)
+{
+    lg_debug_reduce9_kernel<<<1, 64, 0, (hipStream_t)stream_p>>>(in_64x9, out_9);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_reduce9 launch", e);
+    return LG_OK;
+}
+
+extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
+extern "C" const char* lg_last_error(void) { return g_err.c_str(); }
+extern "C" int lg_last_stats(lg_stats* out)
+{
+    if (!out) return LG_ERR_INVALID_ARGUMENT;
+    *out = g_stats;
+    return LG_OK;
+}
+
+extern "C" void lg_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_prof)
+        for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    g_prof.clear();
+}
+
+extern "C" int lg_profile_read(lg_kernel_time* out, int cap)
+{
+    int n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0.0f;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                p.ms += ms; p.n += 1;
+            }
+            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+        }
+        p.pending.clear();
+        if (out && n < cap) {
+            memset(&out[n], 0, sizeof(lg_kernel_time));
+            strncpy(out[n].name, p.name.c_str(), sizeof(out[n].name) - 1);
+            out[n].total_ms = p.ms; out[n].launches = p.n;
+        }
+        n++;
+    }
+    return n;
+}
+

@@ -1,0 +1,395 @@
+// lg_blend.h -- per-tile kernels: K6 lg_blend_fwd (+count), score kernel, K7 lg_blend_bwd and their pair steps / reductions
+// Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
+#pragma once
+
+#include "lg_host.h"
+#include "lg_wave.h"
+
+// ------------------------------------------------------------------------------------------------
+// tile <-> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order); give every
+// XCD a contiguous band of tiles so that neighbouring tiles -- which share Gaussians -- hit the same L2.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles_pad8)
+{
+    const int per = ntiles_pad8 >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+#define LG_Q 64 // LDS queue depth per wave = one batch
+
+// Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
+// every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
+template <bool EXACT>
+__device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
+                                         float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out)
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    const float pe = fminf(power, 0.0f);
+    const float ex = EXACT ? lg_exp(pe) : __expf(pe);
+    const float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    const float test_T = T * (1.0f - alpha);
+    const bool sat = ok && (test_T < LG_T_MIN);
+    const bool contrib = ok && !sat;
+    const float w = alpha * T;
+    const float n0 = fmaf(b.z, w, C0), n1 = fmaf(b.w, w, C1), n2 = fmaf(c.x, w, C2);
+    C0 = contrib ? n0 : C0; C1 = contrib ? n1 : C1; C2 = contrib ? n2 : C2;
+    T = contrib ? test_T : T;
+    last = contrib ? rel : last;
+    done = done || sat;
+    alpha_out = alpha;
+    return contrib;
+}
+
+// K6 / K6c: forward blend
+template <bool COUNT, bool FSCORE, bool EXACT>
+__global__ void __launch_bounds__(256)
+lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
+             float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
+{
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
+    if (tile >= ntiles) return;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
+    const uint2 range = ranges[tile];
+
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = range.x; base < range.y; base += LG_Q) {
+        if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
+        const uint32_t idx = base + lane;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (idx < range.y) {
+            const uint32_t id = point_list[idx];
+            r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+            // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
+            hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
+        }
+        uint64_t mask = __ballot(hit);
+        if (mask == 0) continue;
+        if (hit) {
+            const uint32_t pos = prefix_popc(mask);
+            q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int mycnt = 0;
+        float myf = 0.0f;
+        uint32_t j = 0;
+        const uint32_t rel = base - range.x + 1; // contributor index of source lane 0
+        while (mask) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
+            float alpha = 0.0f, Tprev = T;
+            const int res = fwd_pair<EXACT>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha) ? 1 : 0;
+            if (COUNT) {
+                const uint64_t cm = __ballot(res == 1);
+                if (lane == j) mycnt = (int)__popcll(cm);
+                if (FSCORE) {
+                    float wv = (res == 1) ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
+                    wv = wave_sum_to_lane63(wv);
+                    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
+                    if (lane == j) myf = tot;
+                }
+            }
+            j++;
+        }
+        if (COUNT) {
+            // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
+            if (lane < j && mycnt > 0) {
+                const uint32_t id = __float_as_uint(q2[wave][lane].w);
+                atomicAdd(&count[id], mycnt);
+                if (FSCORE) atomicAdd(&fscore[id], myf);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = fmaf(T, bg[0], C0);
+        out_color[HW + pid] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+    }
+}
+
+// per-view score from the exact integer count (ONE / OPACITY weights)
+__global__ void __launch_bounds__(256)
+lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = count[i];
+    score[i] = c > 0 ? lg_seqsum32(weight ? weight[i] : 1.0f, (uint32_t)c) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: backward blend.  One wave per 16x16 tile, FOUR pixels per lane (the four 8x8 sub-blocks), so a
+// (tile, Gaussian) instance is reduced across lanes once, not once per 8x8 block.  Per batch of 64 list
+// entries: lane l gathers entry l and computes its 4-bit sub-block overlap mask; the wave then walks the
+// batch back to front, evaluating an entry only on the sub-blocks it overlaps (scalar branches on the
+// mask).  The 9 partials are reduced with permlane32/16 swaps + row DPP adds (8 values packed into two
+// registers: ~20 instructions instead of 54), parked in LDS, and flushed once per batch with 64-wide
+// atomics (lane j owns entry j).  acc: [N][12] floats (9 used): dmean2D px x,y | dA dB dC | dopacity | drgb
+typedef unsigned lg_u2v __attribute__((ext_vector_type(2)));
+
+// combine two registers into one: lower 32 lanes = 32-lane partial sums of a, upper 32 lanes = of b
+__device__ __forceinline__ float fold32(float a, float b)
+{
+    lg_u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// rows (16 lanes) of the result: (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    lg_u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+// Sums p[0..8] over the wave and writes the 9 totals to dst[0..8] (LDS).  Which 16-lane row ends up
+// with which value is fixed by the two folds: rows of w0 = (p0, p2, p1, p3), rows of w1 = (p4, p6, p5, p7).
+__device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* dst, uint32_t lane)
+{
+    const float u0 = fold32(p[0], p[1]), u1 = fold32(p[2], p[3]), u2 = fold32(p[4], p[5]), u3 = fold32(p[6], p[7]);
+    float w0 = fold16(u0, u1), w1 = fold16(u2, u3);
+    w0 = row_sum_to_lane15(w0);
+    w1 = row_sum_to_lane15(w1);
+    const float w8 = wave_sum_to_lane63(p[8]);
+    if ((lane & 15u) == 15u) {
+        const uint32_t r = lane >> 4;
+        const uint32_t k = ((r & 1u) << 1) | (r >> 1); // row -> value index inside the group of four
+        dst[k] = w0;
+        dst[4 + k] = w1;
+    }
+    if (lane == 63u) dst[8] = w8;
+}
+
+// One (pixel, Gaussian) step of the back-to-front replay.  EXACT = canonical arithmetic (same sequence as
+// the oracle); otherwise hardware exp / rcp and contraction allowed (training path, 1e-4 contract).
+template <bool EXACT>
+__device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const float4& c, float pxf, float pyf, float& T, float T_final,
+                                         float g0, float g1, float g2, float bg_dot, float& a0, float& a1, float& a2, float& last_alpha,
+                                         float& lc0, float& lc1, float& lc2, float (&p)[9])
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    if (power > 0.0f) return false;
+    const float op = b.y;
+    if (EXACT) {
+        const float G = lg_exp(power);
+        const float alpha = fminf(LG_ALPHA_MAX, op * G);
+        if (alpha < LG_ALPHA_MIN) return false;
+        const float A = -2.0f * a.z, B = -a.w, Cc = -2.0f * b.x;
+        T = T / (1.0f - alpha);
+        const float dch = alpha * T;
+        const float c0 = b.z, c1 = b.w, c2 = c.x;
+        a0 = last_alpha * lc0 + (1.0f - last_alpha) * a0;
+        a1 = last_alpha * lc1 + (1.0f - last_alpha) * a1;
+        a2 = last_alpha * lc2 + (1.0f - last_alpha) * a2;
+        lc0 = c0; lc1 = c1; lc2 = c2;
+        float dL_dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
+        dL_dalpha = dL_dalpha * T;
+        last_alpha = alpha;
+        dL_dalpha = dL_dalpha + (-T_final / (1.0f - alpha)) * bg_dot;
+        const float dL_dG = op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        p[0] += dL_dG * (-gdx * A - gdy * B);
+        p[1] += dL_dG * (-gdy * Cc - gdx * B);
+        p[2] += -0.5f * gdx * dx * dL_dG;
+        p[3] += -gdx * dy * dL_dG;
+        p[4] += -0.5f * gdy * dy * dL_dG;
+        p[5] += G * dL_dalpha;
+        p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+        return true;
+    }
+    return false;
+}
+
+// Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
+// the whole sequence and invalid lanes are neutralised by zeroing dL/dalpha and the colour weight and by
+// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.)
+__device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
+                                              float& T, float T_final, float g0, float g1, float g2, float bg_dot, float& a0, float& a1,
+                                              float& a2, float (&p)[9])
+{
+#pragma clang fp contract(fast)
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
+    const float G = __expf(fminf(power, 0.0f));
+    const float op = b.y;
+    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (0*c + 1*a = a)
+    // and dch = 0, so four of the seven selects of a naive branch-free form disappear (v_cndmask / v_cmp / v_min cost
+    // ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).  T keeps its select: rcp(1.0) need not be exactly 1.
+    const float am = ok ? alpha : 0.0f;
+    const float om = 1.0f - am;
+    const float inv = __builtin_amdgcn_rcpf(om);
+    const float Tn = T * inv;
+    const float c0 = b.z, c1 = b.w, c2 = c.x;
+    // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence)
+    const float dch = am * Tn;
+    float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * Tn - (T_final * inv) * bg_dot;
+    dL_dalpha = ok ? dL_dalpha : 0.0f;
+    T = ok ? Tn : T;
+    a0 = am * c0 + om * a0;
+    a1 = am * c1 + om * a1;
+    a2 = am * c2 + om * a2;
+    const float dL_dG = op * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
+    p[0] += dL_dG * (2.0f * a.z * gdx + a.w * gdy);
+    p[1] += dL_dG * (2.0f * b.x * gdy + a.w * gdx);
+    const float hg = -0.5f * dL_dG;
+    p[2] += hg * gdx * dx;
+    p[3] -= dL_dG * gdx * dy;
+    p[4] += hg * gdy * dy;
+    p[5] += G * dL_dalpha;
+    p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+    return ok;
+}
+
+template <bool EXACT>
+__global__ void __launch_bounds__(64)
+lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad8, const uint2* __restrict__ ranges,
+             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_sorted, const float4* __restrict__ rec,
+             const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+             const float* __restrict__ dL_dpix, float* __restrict__ part)
+{
+    __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
+    __shared__ float stage[LG_Q * 9];
+    const int tile = xcd_tile(blockIdx.x, ntiles_pad8);
+    if (tile >= ntiles) return;
+    const uint32_t lane = threadIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)H * W;
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+
+    float pxf[4], pyf[4], T[4], Tfin[4], g0[4], g1[4], g2[4], bgd[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
+    uint32_t last[4];
+    uint32_t wmax = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int pxi = tx * LG_TILE + (s & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (s >> 1) * 8 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const size_t pid = (size_t)pyi * W + pxi;
+        pxf[s] = (float)pxi; pyf[s] = (float)pyi;
+        Tfin[s] = inside ? final_T[pid] : 0.0f;
+        T[s] = Tfin[s];
+        last[s] = inside ? n_contrib[pid] : 0u;
+        g0[s] = inside ? dL_dpix[pid] : 0.0f;
+        g1[s] = inside ? dL_dpix[HW + pid] : 0.0f;
+        g2[s] = inside ? dL_dpix[2 * HW + pid] : 0.0f;
+        bgd[s] = bgr * g0[s] + bgg * g1[s] + bgb * g2[s];
+        a0[s] = a1[s] = a2[s] = la[s] = lc0[s] = lc1[s] = lc2[s] = 0.0f;
+        wmax = max(wmax, last[s]);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    const uint32_t n_list = range.y - range.x;
+    if (n_list == 0) return;
+    if (wmax > n_list) wmax = n_list;
+    const float tbx = (float)(tx * LG_TILE), tby = (float)(ty * LG_TILE);
+    float4* rows = reinterpret_cast<float4*>(part);
+
+    // every list entry of the tile writes exactly one 48-byte row (zeros when nothing contributed) at its
+    // PRE-SORT slot, where the rows of one Gaussian are contiguous: no zero-fill pass, no atomics, and K9
+    // reads its rows sequentially and sums them in a fixed order (deterministic gradients)
+    for (int k = (int)((n_list - 1) / LG_Q); k >= 0; k--) {
+        const uint32_t base = range.x + (uint32_t)k * LG_Q;
+        const uint32_t nbt = min((uint32_t)LG_Q, n_list - (uint32_t)k * LG_Q);                             // entries of this batch
+        const uint32_t nb = wmax > (uint32_t)k * LG_Q ? min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q) : 0u; // ... that any pixel reached
+        uint64_t hitmask = 0;
+        if (nb > 0) {
+            float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            if (lane < nb) {
+                const uint32_t id = point_list[base + lane];
+                r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+                uint32_t m = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
+                    const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
+                    m |= (hit ? 1u : 0u) << s;
+                }
+                q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int j = (int)nb - 1; j >= 0; j--) {
+                const float4 c = q2[j];
+                const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+                if (m == 0) continue;
+                const float4 a = q0[j], b = q1[j];
+                const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
+                float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                bool contrib = false;
+                {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        if (m & (1u << s)) {
+                            if (EXACT) {
+                                if (rel <= last[s])
+                                    contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
+                                                              la[s], lc0[s], lc1[s], lc2[s], p);
+                            } else {
+                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s],
+                                                         a1[s], a2[s], p);
+                            }
+                        }
+                    }
+                }
+                if (__ballot(contrib) == 0) continue;
+                wave_reduce9_to_lds(p, stage + j * 9, lane);
+                hitmask |= 1ull << j;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < nbt) {
+            float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0;
+            if ((hitmask >> lane) & 1ull) {
+                const float* src = stage + lane * 9;
+                o0 = make_float4(src[0], src[1], src[2], src[3]);
+                o1 = make_float4(src[4], src[5], src[6], src[7]);
+                o2 = make_float4(src[8], 0.0f, 0.0f, 0.0f);
+            }
+            float4* dst = rows + 3 * (size_t)slot_sorted[base + lane];
+            dst[0] = o0; dst[1] = o1; dst[2] = o2;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// diagnostics: wave_reduce9_to_lds on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
+__global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
+{
+    __shared__ float dst[9];
+    float p[9];
+    for (int c = 0; c < 9; c++) p[c] = in[threadIdx.x * 9 + c];
+    wave_reduce9_to_lds(p, dst, threadIdx.x);
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x];
+}
+

@@ -1,0 +1,176 @@
+// lg_host.h -- host-side plumbing: error strings, optional per-kernel hipEvent profiler, scratch-buffer carving (GeomView / ImgView / BinView)
+// Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lightgaussian.h"
+#include "lg_math.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static thread_local lg_stats g_stats = {0, 0};
+
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return fail(LG_ERR_DEVICE, #expr, _e);      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel event timing (LG_FLAG_PROFILE)
+struct ProfEntry { std::string name; double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+// process-wide (autograd runs backward on its own thread), guarded by a mutex
+static std::vector<ProfEntry> g_prof;
+static std::mutex g_prof_mu;
+
+static ProfEntry& prof_entry(const char* name)
+{
+    for (auto& p : g_prof) if (p.name == name) return p;
+    g_prof.emplace_back();
+    g_prof.back().name = name;
+    return g_prof.back();
+}
+struct ProfScope {
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t s; const char* name; bool on;
+    ProfScope(bool on_, const char* n, hipStream_t st) : s(st), name(n), on(on_)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            prof_entry(name).pending.emplace_back(a, b);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// scratch carving (all sub-buffers 256-byte aligned)
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct GeomView {
+    float4* rec;        // [N][3]  blend record {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
+    float4* aux;        // [N][2]  backward record {cov3D[0..3]} {cov3D[4], cov3D[5], clamp-bits, -}
+    uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
+    uint32_t* touched;  // [N]
+    uint32_t* offsets;  // [N] inclusive scan of touched
+    uint32_t* counters; // [16]: 1 = prefiltered violation, 2 = largest depth bit pattern
+    uint32_t* blk_dmax; // [ceil(N/64)] per-workgroup largest depth bit pattern (reduced by lg_reduce_dmax)
+    void* scan_temp; size_t scan_temp_bytes;
+    size_t total;
+};
+
+static size_t scan_temp_bytes_for(int N)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N);
+    return bytes;
+}
+
+static GeomView carve_geom(void* base, int N)
+{
+    GeomView g;
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    size_t n = (size_t)(N > 0 ? N : 1);
+    g.rec = (float4*)take(n * 48);
+    g.aux = (float4*)take(n * 32);
+    g.tinfo = (uint4*)take(n * 16);
+    g.touched = (uint32_t*)take(n * 4);
+    g.offsets = (uint32_t*)take(n * 4);
+    g.counters = (uint32_t*)take(64);
+    g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
+    g.scan_temp_bytes = scan_temp_bytes_for((int)n);
+    g.scan_temp = take(g.scan_temp_bytes);
+    g.total = off;
+    return g;
+}
+
+struct ImgView { float* final_T; uint32_t* n_contrib; size_t total; };
+static ImgView carve_img(void* base, int W, int H)
+{
+    ImgView v; size_t off = 0; char* p = (char*)base; size_t P = (size_t)W * H;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    v.final_T = (float*)take(P * 4);
+    v.n_contrib = (uint32_t*)take(P * 4);
+    v.total = off;
+    return v;
+}
+
+// Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
+// offsets for both key formats.
+struct BinView {
+    uint2* ranges;                  // [tiles]
+    uint32_t* point_list;           // [R] Gaussian ids in (tile, depth, id) order
+    uint32_t* slot_out;             // [R] pre-sort slot of every sorted position (row address of the backward)
+    uint64_t *keys_in, *keys_out;   // [R] radix-sort double buffer
+    uint32_t* slot_in;              // [R] (pairs format only) iota values carried through the sort
+    uint32_t* gid_slot;             // [R] (pairs format only) Gaussian id of every pre-sort slot
+    void* sort_temp; size_t sort_temp_bytes; size_t total;
+};
+static int bits_for(uint32_t n) // smallest b with 2^b >= n
+{
+    int b = 0;
+    while (b < 32 && (1ull << b) < n) b++;
+    return b;
+}
+static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
+{
+    BinView v; memset(&v, 0, sizeof(v)); size_t off = 0; char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    size_t n = (size_t)(R > 0 ? R : 1);
+    const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
+    v.ranges = (uint2*)take((size_t)gx * gy * 8);
+    v.point_list = (uint32_t*)take(n * 4);
+    v.slot_out = (uint32_t*)take(n * 4);
+    v.keys_in = (uint64_t*)take(n * 8);
+    v.keys_out = (uint64_t*)take(n * 8);
+    size_t tb = 0;
+    if (packed) {
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 64);
+    } else {
+        v.slot_in = (uint32_t*)take(n * 4);
+        v.gid_slot = (uint32_t*)take(n * 4);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                                 (uint32_t*)nullptr, (int)n, 0, 64);
+    }
+    v.sort_temp_bytes = tb;
+    v.sort_temp = take(tb);
+    v.total = off;
+    return v;
+}
+
+extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
+extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
+extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H)
+{
+    const size_t a = carve_bin(nullptr, R, W, H, true).total, b = carve_bin(nullptr, R, W, H, false).total;
+    return a > b ? a : b; // upper bound over both key formats
+}
+extern "C" size_t lg_backward_scratch_bytes(int32_t N, int64_t R)
+{
+    (void)N;
+    return align_up((size_t)(R > 0 ? R : 1) * 12 * sizeof(float)); // one 48-byte gradient row per (tile, Gaussian) instance
+}
+

@@ -1,7 +1,7 @@
 // lg_math.h -- per-Gaussian / per-pair arithmetic of the MI355X rasterizer.
 //
 // Pure scalar float code, no wave intrinsics: the same functions are called from the gfx950
-// kernels (lg_kernels.hip) and, compiled with g++ by tests/cpu_harness, from the CPU-side unit
+// kernels (lg_preprocess.h / lg_blend.h, compiled through lg_api.hip) and, compiled with g++ by tests/cpu_harness, from the CPU-side unit
 // tests that pin them bit-for-bit against the oracle.  Everything that feeds a threshold test
 // (power > 0, alpha < 1/255, T < 1e-4, tile rectangles) follows the CANONICAL OPERATION ORDER
 // documented in DESIGN.md section 4: plain IEEE mul/add/div/sqrt with contraction disabled

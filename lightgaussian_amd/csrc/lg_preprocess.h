@@ -1,0 +1,336 @@
+// lg_preprocess.h -- per-Gaussian kernels: K1 lg_preprocess (project / EWA / SH->RGB / culling) and K8+K9 lg_preprocess_bwd
+// Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
+#pragma once
+
+#include "lg_host.h"
+#include "lg_wave.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1: preprocess.  One wave per workgroup, 64 consecutive Gaussians.  The SH rows of the wave (64 x 12M
+// bytes, contiguous in memory) are fetched with coalesced 16-byte loads into LDS -- skipping rows of
+// culled Gaussians -- instead of 48 strided dword loads per lane.
+#define LG_PP 64
+#define LG_SH_MAXF 48 // floats per SH row at M = 16
+#define LG_COOP_ROWS 48u // K9: splats with more tile instances than this are gathered by the whole wave
+
+// cooperative copy of the wave's SH rows into LDS (flat layout, row stride = rowf floats)
+__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int i0, int rows, int rowf, uint64_t need_mask,
+                                              float* lds, uint32_t lane)
+{
+    const float* src = shs + (size_t)i0 * rowf;
+    const int nfl = rows * rowf;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    if (vec_ok) {
+        const int nvec = nfl >> 2;
+        for (int q = (int)lane; q < nvec; q += LG_PP) {
+            const int f = q << 2;
+            // rows are skipped only when a float4 never straddles two rows
+            if ((rowf & 3) == 0 && !((need_mask >> (f / rowf)) & 1ull)) continue;
+            *reinterpret_cast<float4*>(lds + f) = *reinterpret_cast<const float4*>(src + f);
+        }
+        for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) lds[f] = src[f];
+    } else {
+        for (int f = (int)lane; f < nfl; f += LG_PP) lds[f] = src[f];
+    }
+}
+
+// RAW (section 8f row 1, "fused getters"): the inputs are GaussianModel's raw parameters -- log-scales, unnormalised
+// quaternions, opacity logits, and the SH coefficients as the two tensors _features_dc [N,1,3] / _features_rest
+// [N,M-1,3] -- and the activations (scene/gaussian_model.py:98-118) are evaluated here instead of by torch.
+__device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <bool RAW>
+__global__ void __launch_bounds__(LG_PP)
+lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
+              const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+              const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+              const float* __restrict__ colors_precomp,
+              const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+              const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
+{
+    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    const uint32_t lane = threadIdx.x;
+    const int i0 = blockIdx.x * LG_PP;
+    const int i = i0 + (int)lane;
+    float vm[16], pm[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
+    cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+    bool vis = false;
+    float px = 0, py = 0, pz = 0, op = 0;
+    float cov[6] = {0, 0, 0, 0, 0, 0};
+    LgSplat sp;
+    if (i < N) {
+        px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2];
+        // near-plane test first so culled Gaussians cost 12 bytes of reads
+        const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+        if (vz > 0.2f) {
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov[k] = cov3D_precomp[6 * (size_t)i + k];
+            } else {
+                float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+                const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+                float q[4] = { q4.x, q4.y, q4.z, q4.w };
+                if (RAW) {
+                    sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                    const float inv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); // F.normalize
+                    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+                }
+                lg_cov3d(sc, mod, q, cov);
+            }
+            op = RAW ? lg_sigmoid(opacities[i]) : opacities[i];
+            vis = lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp);
+        } else if (prefiltered) {
+            g.counters[1] = 1u;
+        }
+    }
+    const uint64_t vmask = __ballot(vis);
+    const bool split = RAW && shs_rest != nullptr;        // dc and rest are separate tensors
+    const int rowf = split ? 3 * (M - 1) : 3 * M;          // floats per LDS-staged row
+    if (shs && vmask && rowf > 0) {
+        stage_sh_rows(split ? shs_rest : shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (i < N) {
+        uint32_t touched = 0;
+        int radius = 0;
+        if (vis) {
+            radius = sp.radius;
+            touched = (uint32_t)((sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0));
+            float rgb[3];
+            uint32_t cb = 0;
+            if (colors_precomp) {
+                rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
+            } else {
+                float sh[LG_SH_MAXF];
+                const float* row = sh_rows + lane * rowf;
+                const int nact = (D + 1) * (D + 1) * 3;
+                if (split) {
+                    sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+#pragma unroll
+                    for (int k = 3; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k - 3] : 0.0f;
+                } else if ((rowf & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < LG_SH_MAXF / 4; q++) {
+                        float4 v4 = make_float4(0, 0, 0, 0);
+                        if (q * 4 < nact) v4 = reinterpret_cast<const float4*>(row)[q];
+                        sh[4 * q] = v4.x; sh[4 * q + 1] = v4.y; sh[4 * q + 2] = v4.z; sh[4 * q + 3] = v4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
+                }
+                lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
+            }
+            g.rec[3 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
+            g.rec[3 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
+            g.rec[3 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
+            g.aux[2 * (size_t)i + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
+            g.aux[2 * (size_t)i + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
+            g.tinfo[i] = make_uint4((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16),
+                                    __float_as_uint(sp.depth), 0u);
+        }
+        radii[i] = radius;
+        g.touched[i] = touched;
+    }
+    // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
+    // largest depth of the workgroup (bit pattern; positive floats order like integers), for the packed sort key.
+    // Written per workgroup and reduced by a one-block kernel: a shared atomicMax serialises the first ~3k waves.
+    uint32_t dmax = vis ? __float_as_uint(sp.depth) : 0u;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, sh));
+    if (lane == 0) g.blk_dmax[blockIdx.x] = dmax;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K8 + K9 fused: per-Gaussian backward.  One wave per workgroup; SH rows in and dL/dSH rows out go
+// through LDS so that global traffic is coalesced 16-byte accesses.
+template <bool RAW>
+__global__ void __launch_bounds__(LG_PP)
+lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
+                  const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+                  const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                  const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                  const int32_t* __restrict__ radii, const float4* __restrict__ aux, const uint32_t* __restrict__ touched,
+                  const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
+                  float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
+                  float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                  float* __restrict__ dL_dscales, float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+{
+    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    const uint32_t lane = threadIdx.x;
+    const int i0 = blockIdx.x * LG_PP;
+    const int i = i0 + (int)lane;
+    float vm[16], pm[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
+    cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+    const bool vis = (i < N) && radii[i] > 0;
+    const uint64_t vmask = __ballot(vis);
+    const bool split = RAW && shs_rest != nullptr;
+    const int rowf = split ? 3 * (M - 1) : 3 * M;
+    const int rows = min(LG_PP, N - i0);
+    const bool use_sh = (shs != nullptr) && (dL_dshs != nullptr);
+    if (use_sh && vmask && rowf > 0) {
+        stage_sh_rows(split ? shs_rest : shs, i0, rows, rowf, vmask, sh_rows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // Screen-filling splats own thousands of gradient rows; a single lane walking them would stall its wave for
+    // milliseconds.  Such lanes are served one at a time by the whole wave: 64 rows per step, then a wave reduction.
+    const uint32_t my_t = vis ? touched[i] : 0u;
+    const uint32_t my_u0 = vis ? offsets[i] - my_t : 0u;
+    float coop[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        uint64_t big = __ballot(my_t > LG_COOP_ROWS);
+        while (big) {
+            const int src = (int)__builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, src);
+            const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)my_u0, src);
+            float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t u = u0 + lane; u < u0 + t; u += LG_PP) {
+                const float4* rp = part + 3 * (size_t)u;
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                acc9[0] += v0.x; acc9[1] += v0.y; acc9[2] += v0.z; acc9[3] += v0.w; acc9[4] += v1.x; acc9[5] += v1.y; acc9[6] += v1.z;
+                acc9[7] += v1.w; acc9[8] += v2.x;
+            }
+#pragma unroll
+            for (int k9 = 0; k9 < 9; k9++) {
+                const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(acc9[k9])), 63));
+                if ((int)lane == src) coop[k9] = tot;
+            }
+        }
+    }
+    float m2[3] = {0, 0, 0}, m3[3] = {0, 0, 0}, dop = 0.0f, dsc[3] = {0, 0, 0}, drot[4] = {0, 0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
+    float dcol[3] = {0, 0, 0};
+    float dsh[LG_SH_MAXF];
+#pragma unroll
+    for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = 0.0f;
+    if (vis) {
+        // gather this Gaussian's gradient rows (one per tile instance) in slot order: deterministic, no atomics.
+        // Splats with more than LG_COOP_ROWS instances were summed cooperatively by the whole wave (below).
+        float a[9];
+#pragma unroll
+        for (int k9 = 0; k9 < 9; k9++) a[k9] = coop[k9];
+        if (my_t <= LG_COOP_ROWS) {
+            for (uint32_t u = my_u0; u < my_u0 + my_t; u++) {
+                const float4* rp = part + 3 * (size_t)u;
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w; a[8] += v2.x;
+            }
+        }
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        const float4 x0 = aux[2 * (size_t)i], x1 = aux[2 * (size_t)i + 1];
+        float S[6] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y };
+        LgGradOut go;
+        lg_backward_geom(vm, pm, px, py, pz, S, a, W, H, tanfovx, tanfovy, go);
+        m2[0] = go.mean2D[0]; m2[1] = go.mean2D[1];
+        m3[0] = go.mean3D[0]; m3[1] = go.mean3D[1]; m3[2] = go.mean3D[2];
+        dop = a[5];
+        if (colors_precomp) {
+            dcol[0] = a[6]; dcol[1] = a[7]; dcol[2] = a[8];
+        } else if (use_sh) {
+            const uint32_t cb = __float_as_uint(x1.z);
+            float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
+            float sh[LG_SH_MAXF];
+            const float* row = sh_rows + lane * rowf;
+            const int nact = (D + 1) * (D + 1) * 3;
+            if (split) {
+                sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+#pragma unroll
+                for (int k = 3; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k - 3] : 0.0f;
+            } else if ((rowf & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < LG_SH_MAXF / 4; q++) {
+                    float4 v4 = make_float4(0, 0, 0, 0);
+                    if (q * 4 < nact) v4 = reinterpret_cast<const float4*>(row)[q];
+                    sh[4 * q] = v4.x; sh[4 * q + 1] = v4.y; sh[4 * q + 2] = v4.z; sh[4 * q + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
+            }
+            lg_backward_sh(D, sh, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh[k * 3 + c] = v; });
+        }
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov[k] = go.cov3D[k];
+        } else {
+            float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
+            const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+            float q[4] = { q4.x, q4.y, q4.z, q4.w };
+            float qn = 1.0f;
+            if (RAW) {
+                sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+                const float inv = 1.0f / qn;
+                q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+            }
+            lg_backward_cov3d(sc, mod, q, go.cov3D, dsc, drot);
+            if (RAW) {
+                // exp: d/draw = d/ds * s ; normalize: d/dr = (g - q (q.g)) / |r|
+                dsc[0] *= sc[0]; dsc[1] *= sc[1]; dsc[2] *= sc[2];
+                const float qg = q[0] * drot[0] + q[1] * drot[1] + q[2] * drot[2] + q[3] * drot[3];
+                const float inv = 1.0f / qn;
+#pragma unroll
+                for (int k = 0; k < 4; k++) drot[k] = (drot[k] - q[k] * qg) * inv;
+            }
+        }
+        if (RAW) { // sigmoid: d/dlogit = d/dsigma * sigma (1 - sigma)
+            const float sg = lg_sigmoid(opacities[i]);
+            dop = dop * sg * (1.0f - sg);
+        }
+    }
+    if (use_sh) {
+        // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced
+        __builtin_amdgcn_wave_barrier();
+        float* row = sh_rows + lane * rowf;
+        if (split) {
+            if (i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
+#pragma unroll
+            for (int k = 3; k < LG_SH_MAXF; k++)
+                if (k - 3 < rowf) row[k - 3] = dsh[k];
+        } else if ((rowf & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < LG_SH_MAXF / 4; q++)
+                if (q * 4 < rowf) reinterpret_cast<float4*>(row)[q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LG_SH_MAXF; k++)
+                if (k < rowf) row[k] = dsh[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dst = (split ? dL_dshs_rest : dL_dshs) + (size_t)i0 * rowf;
+        const int nfl = rows * rowf;
+        if (nfl > 0) {
+            if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+                const int nvec = nfl >> 2;
+                for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(sh_rows)[q];
+                for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+            } else {
+                for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+            }
+        }
+    }
+    if (i >= N) return;
+    dL_dmeans2D[3 * (size_t)i] = m2[0]; dL_dmeans2D[3 * (size_t)i + 1] = m2[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
+    dL_dmeans3D[3 * (size_t)i] = m3[0]; dL_dmeans3D[3 * (size_t)i + 1] = m3[1]; dL_dmeans3D[3 * (size_t)i + 2] = m3[2];
+    dL_dopacity[i] = dop;
+    if (dL_dcolors) { dL_dcolors[3 * (size_t)i] = dcol[0]; dL_dcolors[3 * (size_t)i + 1] = dcol[1]; dL_dcolors[3 * (size_t)i + 2] = dcol[2]; }
+    if (dL_dscales) { dL_dscales[3 * (size_t)i] = dsc[0]; dL_dscales[3 * (size_t)i + 1] = dsc[1]; dL_dscales[3 * (size_t)i + 2] = dsc[2]; }
+    if (dL_drots) *reinterpret_cast<float4*>(dL_drots + 4 * (size_t)i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
+}
+
