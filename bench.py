@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--views", type=int, default=200, help="cameras on the orbit; steps cycle through them")
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=0.004, help="median world-space sigma of the synthetic Gaussians (frozen workload: 0.004)")
     ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
     ap.add_argument("--fused", action="store_true", help="render_fused (SURVEY 8f row 1 extension): getters inside the kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +100,7 @@ def main():
     _lib.load()
     rasterizer.set_option("fast_exp", not args.exact_exp)
     N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2
-    g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree)
+    g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree, log_scale_mean=math.log(args.scale))
     pc = g_cpu.to(dev)
     pipe = syn.PipelineParams()
     bg = torch.zeros(3, device=dev)  # black, prune_finetune.py:87-88
