@@ -246,33 +246,63 @@ def main():
 
 
 def cpu_baseline(args, g_cpu, W, H):
-    """Time the CPU oracle (a port: the reference has no CPU render path) on ONE view of
-    the same workload; the sample shrinks to 1M Gaussians when the full one would take too long."""
+    """Time the CPU oracle (a port: the reference has no CPU render path) on ONE view of the same
+    workload, and -- since the oracle output is there anyway -- report full-size parity of the HIP path against it
+    on the very same inputs (PSNR of the image, max error, gradient error / hit-count equality)."""
     import numpy as np
     from lightgaussian_amd import synthetic as syn
+    from lightgaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from oracle import oracle
     oracle.build()
     cores = os.cpu_count() or 1
     n = args.cpu_baseline_n or g_cpu.num
     cam = syn.orbit_camera(0, args.views, W, H)
+    M = (args.sh_degree + 1) ** 2
     with torch.no_grad():
-        kw = dict(means3D=g_cpu.get_xyz[:n].numpy(), opacities=g_cpu.get_opacity[:n].numpy(), W=W, H=H,
-                  tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=np.zeros(3, np.float32),
-                  viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
-                  campos=cam.camera_center.numpy(), sh_degree=args.sh_degree, shs=g_cpu.get_features[:n].numpy(),
-                  scales=g_cpu.get_scaling[:n].numpy(), rotations=g_cpu.get_rotation[:n].numpy())
+        t = dict(means3D=g_cpu.get_xyz[:n].contiguous(), opacities=g_cpu.get_opacity[:n].contiguous(),
+                 shs=g_cpu.get_features[:n, :M].contiguous(), scales=g_cpu.get_scaling[:n].contiguous(),
+                 rotations=g_cpu.get_rotation[:n].contiguous())
+        kw = dict({k: v.numpy() for k, v in t.items()}, W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                  bg=np.zeros(3, np.float32), viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+                  campos=cam.camera_center.numpy(), sh_degree=args.sh_degree)
+    count = args.mode == "count"
     t0 = time.perf_counter()
-    f = oracle.forward(count=(args.mode == "count"), **kw)
+    f = oracle.forward(count=count, **kw)
     t_f = time.perf_counter() - t0
     t_b = 0.0
+    gimg = np.random.RandomState(0).randn(3, H, W).astype(np.float32) / (3 * H * W)
     if args.mode == "fwdbwd":
-        gimg = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
         t0 = time.perf_counter()
-        oracle.backward(f, gimg)
+        gref = oracle.backward(f, gimg)
         t_b = time.perf_counter() - t0
-    return {"value": round(1.0 / (t_f + t_b), 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"1 view, {n} Gaussians, {W}x{H}, {args.mode} (oracle/lg_oracle.c, OpenMP, fp32; fwd {t_f:.2f}s bwd {t_b:.2f}s; "
-                      "rasterizer only, no getters/loss)"}
+    out = {"value": round(1.0 / (t_f + t_b), 4), "unit": "views/s", "cores": cores, "kind": "port",
+           "sample": f"1 view, {n} Gaussians, {W}x{H}, {args.mode} (oracle/lg_oracle.c, OpenMP, fp32; fwd {t_f:.2f}s bwd {t_b:.2f}s; "
+                     "rasterizer only, no getters/loss)"}
+    # ---- parity of the HIP path on the same inputs (same activations, computed on the CPU) ----
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = {k: v.to(dev).requires_grad_(args.mode == "fwdbwd") for k, v in t.items()}
+    means2D = torch.zeros((n, 3), device=dev, requires_grad=args.mode == "fwdbwd")
+    camd = cam.to(dev)
+    rs = GaussianRasterizationSettings(H, W, kw["tanfovx"], kw["tanfovy"], torch.zeros(3, device=dev), 1.0, camd.world_view_transform,
+                                       camd.full_proj_transform, args.sh_degree, camd.camera_center, False, False, count)
+    res = GaussianRasterizer(rs)(means3D=d["means3D"], means2D=means2D, opacities=d["opacities"], shs=d["shs"], scales=d["scales"],
+                                 rotations=d["rotations"])
+    img = (res[2] if count else res[0])
+    err = (img.detach().cpu().numpy().astype(np.float64) - f.color.astype(np.float64))
+    mse = float((err ** 2).mean())
+    par = {"image_psnr_db": (round(10 * math.log10(1.0 / mse), 2) if mse > 0 else "inf (bit-identical)"),
+           "image_max_abs_err": float(np.abs(err).max()), "radii_equal": bool(np.array_equal(res[-1].cpu().numpy(), f.radii))}
+    if count:
+        par["hit_counts_equal"] = bool(np.array_equal(res[0].cpu().numpy(), f.count))
+        par["scores_bit_identical"] = bool(np.array_equal(res[1].cpu().numpy().view(np.uint32), f.score.view(np.uint32)))
+    if args.mode == "fwdbwd":
+        (img * torch.from_numpy(gimg).to(dev)).sum().backward()
+        rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+        par["grad_max_rel_err"] = {k: float(f"{rel(d[k].grad.cpu().numpy().reshape(gref[k].shape), gref[k]):.3e}") for k in
+                                   ("means3D", "opacities", "shs", "scales", "rotations")}
+        par["grad_max_rel_err"]["means2D"] = float(f"{rel(means2D.grad.cpu().numpy(), gref['means2D']):.3e}")
+    out["parity_vs_oracle_same_inputs"] = par
+    return out
 
 
 if __name__ == "__main__":

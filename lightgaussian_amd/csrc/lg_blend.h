@@ -16,6 +16,21 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad8)
 
 #define LG_Q 64 // LDS queue depth per wave = one batch
 
+// Threshold guard of the hardware-exp variants.  alpha >= 1/255 is a discontinuity of the algorithm: a pair
+// that flips in or out changes its pixel by up to T/255.  v_exp_f32 and the canonical lg_exp differ by a few 1e-7
+// relative, so on the rare lanes whose alpha lies within 5e-6 (relative) of the threshold the canonical value is
+// used instead (wave-uniform branch, taken for ~1e-5 of the evaluations).  Every include/exclude decision of the
+// fast path then equals the canonical path's, forward and backward alike.
+__device__ __forceinline__ float guard_alpha(float alpha, float opacity, float power_le0)
+{
+    const bool near = fabsf(alpha - LG_ALPHA_MIN) < 2.0e-8f;
+    if (__ballot(near) != 0) {
+        const float ac = fminf(LG_ALPHA_MAX, opacity * lg_exp(power_le0));
+        alpha = near ? ac : alpha;
+    }
+    return alpha;
+}
+
 // Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
 // every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
 template <bool EXACT>
@@ -26,7 +41,8 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
     const float pe = fminf(power, 0.0f);
     const float ex = EXACT ? lg_exp(pe) : __expf(pe);
-    const float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+    float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+    if (!EXACT) alpha = guard_alpha(alpha, b.y, pe);
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
@@ -235,9 +251,10 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 #pragma clang fp contract(fast)
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
-    const float G = __expf(fminf(power, 0.0f));
+    const float pe = fminf(power, 0.0f);
+    const float G = __expf(pe);
     const float op = b.y;
-    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+    const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, pe); // same decisions as the forward
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (0*c + 1*a = a)
     // and dch = 0, so four of the seven selects of a naive branch-free form disappear (v_cndmask / v_cmp / v_min cost

@@ -317,3 +317,43 @@ def test_debug_flag_prefiltered_error_and_stale_count_api():
     # markVisible: frustum (near plane) test only
     vis = GaussianRasterizer(settings()).markVisible(bad["means3D"])
     assert not bool(vis[0]) and bool(vis[1:].all())
+
+
+def test_full_size_prune_mask_parity():
+    """BASELINE contract at full size: 3M Gaussians, 1080p, several views: summed hit counts and significance scores
+    bit-identical to the oracle, prune mask (v_pow 0.1, 66 %) Hamming distance 0."""
+    from lightgaussian_amd import prune as lg_prune
+    from lightgaussian_amd.gaussian_renderer import count_render
+    dev = torch.device("cuda:0")
+    N, W, H, V = 3_000_000, 1920, 1080, 3
+    g = syn.make_gaussians(N)
+    cams = [syn.orbit_camera(17 * k + 3, 200, W, H) for k in range(V)]
+    # activations evaluated ONCE on the CPU so that oracle and HIP path see identical inputs
+    with torch.no_grad():
+        frozen = syn.SyntheticGaussians(g.get_xyz, g._features_dc, g._features_rest, g.get_scaling, g.get_rotation, g.get_opacity, 3, 3)
+    class _PC:
+        get_xyz = frozen._xyz.to(dev); get_scaling = frozen._scaling.to(dev); get_rotation = frozen._rotation.to(dev)
+        get_opacity = frozen._opacity.to(dev); get_features = torch.cat((frozen._features_dc, frozen._features_rest), 1).to(dev)
+        active_sh_degree = 3; max_sh_degree = 3
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        cnt, imp = lg_prune.prune_list(_PC, [c.to(dev) for c in cams], syn.PipelineParams(), bg)
+    cnt_o = None
+    for cam in cams[::-1]:                       # the reference loop pops from the end
+        kw = dict(means3D=frozen._xyz.numpy(), opacities=frozen._opacity.numpy(), W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5),
+                  tanfovy=math.tan(cam.FoVy * 0.5), bg=np.zeros(3, np.float32), viewmatrix=cam.world_view_transform.numpy(),
+                  projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), sh_degree=3,
+                  shs=_PC.get_features.cpu().numpy(), scales=frozen._scaling.numpy(), rotations=frozen._rotation.numpy())
+        f = oracle.forward(count=True, **kw)
+        if cnt_o is None:
+            cnt_o, imp_o = f.count.copy(), f.score.copy()
+        else:
+            cnt_o += f.count; imp_o += f.score
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.array_equal(imp.cpu().numpy().view(np.uint32), imp_o.view(np.uint32))
+    v = lg_prune.calculate_v_imp_score(_PC, imp, 0.1)
+    mask = lg_prune.prune_mask(0.66, v).cpu().numpy()
+    v_o = lg_prune.calculate_v_imp_score(_PC, torch.from_numpy(imp_o).to(dev), 0.1)
+    mask_o = lg_prune.prune_mask(0.66, v_o).cpu().numpy()
+    assert int(np.count_nonzero(mask != mask_o)) == 0
+    assert 0.6 < mask.mean() < 0.8
