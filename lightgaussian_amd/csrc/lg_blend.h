@@ -47,9 +47,9 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
     const bool contrib = ok && !sat;
-    const float w = alpha * T;
-    const float n0 = fmaf(b.z, w, C0), n1 = fmaf(b.w, w, C1), n2 = fmaf(c.x, w, C2);
-    C0 = contrib ? n0 : C0; C1 = contrib ? n1 : C1; C2 = contrib ? n2 : C2;
+    // one select on the weight instead of three on the colours: fmaf(rgb, 0, C) == C bit for bit (finite rgb)
+    const float w = contrib ? alpha * T : 0.0f;
+    C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
     T = contrib ? test_T : T;
     last = contrib ? rel : last;
     done = done || sat;
