@@ -357,3 +357,35 @@ def test_full_size_prune_mask_parity():
     mask_o = lg_prune.prune_mask(0.66, v_o).cpu().numpy()
     assert int(np.count_nonzero(mask != mask_o)) == 0
     assert 0.6 < mask.mean() < 0.8
+
+
+def test_render_pipe_alternates_match():
+    """PipelineParams.convert_SHs_python / compute_cov3D_python (arguments/__init__.py:72-77): the four input
+    variants of render() (shs vs colors_precomp, scales+rotations vs cov3D_precomp) give the same image and radii,
+    and gradients reach the raw parameters in every variant (gaussian_renderer/__init__.py:79-99)."""
+    import gpu_common
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    W, H, N = 160, 120, 3000
+    cam = syn.orbit_camera(2, 7, W, H, radius=5.0).to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = None
+    for sh_py in (False, True):
+        for cov_py in (False, True):
+            g = syn.make_gaussians(N, seed=9, log_scale_mean=math.log(0.05), opacity_mean=0.0, extent=(2, 1.2, 2)).to(dev)
+            g.requires_grad_(True)
+            pipe = syn.PipelineParams(convert_SHs_python=sh_py, compute_cov3D_python=cov_py)
+            pkg = render(cam, g, pipe, bg)
+            (pkg["render"] * gimg).sum().backward()
+            out = (pkg["render"].detach().cpu().numpy(), pkg["radii"].cpu().numpy(), g._xyz.grad.cpu().numpy(),
+                   g._features_dc.grad.cpu().numpy(), g._scaling.grad.cpu().numpy(), pkg["viewspace_points"].grad.cpu().numpy())
+            assert set(pkg.keys()) == {"render", "viewspace_points", "visibility_filter", "radii"}
+            assert pkg["visibility_filter"].dtype == torch.bool
+            if ref is None:
+                ref = out
+                continue
+            assert np.array_equal(out[1], ref[1])
+            assert gpu_common.rel_err(out[0], ref[0]) <= 1e-5
+            for a, b in zip(out[2:], ref[2:]):
+                assert gpu_common.rel_err(a, b) <= TOL
