@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count"], default="fwdbwd")
+    ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count", "distill"], default="fwdbwd")
     ap.add_argument("--n-gaussians", type=int, default=3_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -120,6 +120,14 @@ def main():
         del pert
     pc.requires_grad_(args.mode == "fwdbwd")
     params = [pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity]
+    student = None
+    if args.mode == "distill":
+        # config C5 (distill_train.py:124-146): teacher = these Gaussians at SH degree D, student = the same with
+        # degree D-1 (onedownSHdegree); per step: teacher render (no grad), student render, L1 between the two, backward
+        # through the student, gradients averaged across ranks (bucketed RCCL all-reduce)
+        from lightgaussian_amd import parallel
+        student = parallel.make_student(pc, max(args.sh_degree - 1, 0)).requires_grad_(True)
+        sparams = [student._xyz, student._features_dc, student._features_rest, student._scaling, student._rotation, student._opacity]
 
     def step(i):
         k = my_views[i % len(my_views)]
@@ -134,6 +142,14 @@ def main():
         elif args.mode == "fwd":
             with torch.no_grad():
                 render(cams[k], pc, pipe, bg)
+        elif args.mode == "distill":
+            for p in sparams:
+                p.grad = None
+            with torch.no_grad():
+                target = render(cams[k], pc, pipe, bg)["render"]
+            loss = (render(cams[k], student, pipe, bg)["render"] - target).abs().mean()
+            loss.backward()
+            parallel.allreduce_gradients(sparams)
         else:
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
@@ -184,7 +200,7 @@ def main():
         stats = _lib.last_stats()
         R, P = int(stats["num_rendered"]), W * H
         result = {
-            "metric": "views/sec fwd+bwd @1080p (N Gaussians)" if args.mode == "fwdbwd" else f"views/sec {args.mode} @1080p (N Gaussians)",
+            "metric": "views/sec fwd+bwd @1080p (N Gaussians)" if args.mode == "fwdbwd" else f"views/sec {args.mode} @{H}p (N Gaussians)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -14,3 +14,5 @@ run --n-gaussians 3000000 --mode fwdbwd --steps 100 --fused
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp
 run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwdbwd --steps 50 --sh-degree 2
 run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwd --steps 50 --sh-degree 3
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode distill --steps 30 --sh-degree 3
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode distill --steps 30 --sh-degree 3 --fused
