@@ -221,15 +221,15 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
-    float* acc = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
+    float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
             lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
-                                                                 img.final_T, img.n_contrib, dL_dcolor, acc);
+                                                                 img.final_T, img.n_contrib, dL_dcolor, rows);
         else
             lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
-                                                                img.final_T, img.n_contrib, dL_dcolor, acc);
+                                                                img.final_T, img.n_contrib, dL_dcolor, rows);
     }
     KCHECK("lg_blend_bwd");
     {
@@ -238,7 +238,7 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     lg_preprocess_bwd<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(                                                           \
         N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
         g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched,  \
-        geo.offsets, reinterpret_cast<const float4*>(acc), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
         if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
 #undef LAUNCH_PPB

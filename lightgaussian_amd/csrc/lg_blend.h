@@ -158,8 +158,9 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
 // entries: lane l gathers entry l and computes its 4-bit sub-block overlap mask; the wave then walks the
 // batch back to front, evaluating an entry only on the sub-blocks it overlaps (scalar branches on the
 // mask).  The 9 partials are reduced with permlane32/16 swaps + row DPP adds (8 values packed into two
-// registers: ~20 instructions instead of 54), parked in LDS, and flushed once per batch with 64-wide
-// atomics (lane j owns entry j).  acc: [N][12] floats (9 used): dmean2D px x,y | dA dB dC | dopacity | drgb
+// registers: ~20 instructions instead of 54), parked in LDS, and written once per batch as 48-byte gradient
+// rows (lane j owns entry j): part [R][12] floats (9 used) = dmean2D px x,y | dA dB dC | dopacity | drgb,
+// addressed by the instance's pre-sort slot -- no atomics, every row written exactly once.
 typedef unsigned lg_u2v __attribute__((ext_vector_type(2)));
 
 // combine two registers into one: lower 32 lanes = 32-lane partial sums of a, upper 32 lanes = of b
