@@ -43,6 +43,24 @@ def prune_mask(percent, import_score):
     return (import_score <= value_nth_percentile).squeeze()
 
 
+def calculate_v_imp_score_select(gaussians, imp_list, v_pow):
+    """calculate_v_imp_score with a radix SELECT instead of a full descending sort: the
+    element at index int(N*0.9) of the descending order is the (N - index)-th smallest.  Same value, same v_list."""
+    volume = torch.prod(gaussians.get_scaling, dim=1)
+    n = volume.shape[0]
+    index = int(n * 0.9)
+    kth_percent_largest = torch.kthvalue(volume, n - index).values
+    return torch.pow(volume / kth_percent_largest, v_pow) * imp_list
+
+
+def prune_mask_select(percent, import_score):
+    """prune_mask with one radix select: threshold = (index+1)-th smallest value, index = int(percent*(N-1))."""
+    score = import_score.reshape(-1)
+    index_nth_percentile = int(percent * (score.shape[0] - 1))
+    value_nth_percentile = torch.kthvalue(score, index_nth_percentile + 1).values
+    return (import_score <= value_nth_percentile).squeeze()
+
+
 class _FrozenGetters:
     """The Gaussians do not change during a significance pass, so the activations and the cat() of
     GaussianModel's getters (scene/gaussian_model.py:98-118) are evaluated ONCE instead of once per view

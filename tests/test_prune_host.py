@@ -101,3 +101,20 @@ def test_mask_threshold_semantics_ties_pruned():
     assert m.tolist() == [True, True, True] + [False] * 7
     m = lg_prune.prune_mask(0.66, score)     # index int(0.66*9)=5 -> thr 3.0
     assert m.sum().item() == 6
+
+
+def test_select_based_epilogue_is_bit_identical_to_sort_based():
+    g = torch.Generator().manual_seed(3)
+    for n in (10, 1000, 50001):
+        scal = torch.exp(torch.randn(n, 3, generator=g) * 0.8 - 4.0)
+        imp = torch.rand(n, generator=g) * 100
+        imp[torch.rand(n, generator=g) < 0.3] = 0.0
+
+        class GM:
+            get_scaling = scal
+        for v_pow in (0.1, 0.5):
+            a = lg_prune.calculate_v_imp_score(GM, imp, v_pow)
+            b = lg_prune.calculate_v_imp_score_select(GM, imp, v_pow)
+            assert torch.equal(a, b)
+            for pct in (0.0, 0.1, 0.66, 1.0):
+                assert torch.equal(lg_prune.prune_mask(pct, a), lg_prune.prune_mask_select(pct, a))
