@@ -85,12 +85,17 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
         {
             ProfScope ps(prof, "preprocess", stream);
-#define LAUNCH_PP(RAWP)                                                                                                              \
-    lg_preprocess<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,           \
+#define LAUNCH_PP(RAWP, DIR)                                                                                                         \
+    lg_preprocess<RAWP, DIR><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,      \
                                                                       v->scale_modifier, v->prefiltered, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
-            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PP(true); else LAUNCH_PP(false);
+            // rows that are whole float4s and 16-byte aligned are read directly (no LDS); anything else is staged through LDS
+            const bool direct = g->shs && !g->shs_rest && (g->M % 4 == 0) && ((reinterpret_cast<uintptr_t>(g->shs) & 15u) == 0) &&
+                                getenv("LG_K1_LDS") == nullptr;
+            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PP(true, false);
+            else if (direct) LAUNCH_PP(false, true);
+            else LAUNCH_PP(false, false);
 #undef LAUNCH_PP
         }
         KCHECK("lg_preprocess");

@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
 // [N,M-1,3] -- and the activations (scene/gaussian_model.py:98-118) are evaluated here instead of by torch.
 __device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <bool RAW>
+template <bool RAW, bool DIRECT>
 __global__ void __launch_bounds__(LG_PP)
 lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
               const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
@@ -48,7 +48,9 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
 {
-    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    // DIRECT: every visible lane reads its own 16-byte-aligned SH row with float4 loads and no LDS is allocated
+    // (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3); otherwise rows go through LDS.
+    __shared__ __attribute__((aligned(16))) float sh_rows[DIRECT ? 4 : LG_PP * LG_SH_MAXF];
     const uint32_t lane = threadIdx.x;
     const int i0 = blockIdx.x * LG_PP;
     const int i = i0 + (int)lane;
@@ -88,7 +90,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;        // dc and rest are separate tensors
     const int rowf = split ? 3 * (M - 1) : 3 * M;          // floats per LDS-staged row
-    if (shs && vmask && rowf > 0) {
+    if (!DIRECT && shs && vmask && rowf > 0) {
         stage_sh_rows(split ? shs_rest : shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -106,7 +108,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
             } else {
                 float sh[LG_SH_MAXF];
-                const float* row = sh_rows + lane * rowf;
+                const float* row = DIRECT ? shs + (size_t)i * rowf : sh_rows + lane * rowf;
                 const int nact = (D + 1) * (D + 1) * 3;
                 if (split) {
                     sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
