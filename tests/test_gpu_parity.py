@@ -27,12 +27,16 @@ CASES = [
     dict(N=1500, W=96, H=64, seed=5, scale=0.03, opm=0.0, ext=(2, 1, 2), deg=0, precolor=True),
     dict(N=1500, W=96, H=64, seed=6, scale=0.03, opm=0.0, ext=(2, 1, 2), deg=3, precov=True),
     dict(N=300, W=320, H=240, seed=7, scale=0.6, opm=-1.5, ext=(2, 1, 2), deg=3),            # screen-filling splats: >48 tile instances each (cooperative row gather in K9)
+    dict(N=1500, W=100, H=100, seed=8, scale=0.05, opm=0.5, ext=(2, 1, 2), deg=3, aniso=True),  # needle-like splats: ill-conditioned conics fall back to the full rectangle
 ]
 
 
 def _scene(c):
     g = syn.make_gaussians(c["N"], seed=c["seed"], log_scale_mean=math.log(c["scale"]), opacity_mean=c["opm"],
                            extent=c["ext"], log_scale_std=0.9)
+    if c.get("aniso"):
+        g._scaling[:, 0] += 3.0
+        g._scaling[:, 1] -= 2.0
     cam = syn.orbit_camera(1, 5, c["W"], c["H"], radius=5.0)
     pre = torch.rand(c["N"], 3, generator=torch.Generator().manual_seed(7)) if c.get("precolor") else None
     return common.scene_kwargs(g, cam, c["W"], c["H"], deg=c["deg"], precolor=pre, precov=c.get("precov", False),
