@@ -76,8 +76,6 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
     GeomView geo = carve_geom(geom_p, N);
     ImgView img = carve_img(img_p, W, H);
-    const size_t HW = (size_t)W * H;
-
     if (binning_out) *binning_out = nullptr;
     if (num_rendered) *num_rendered = 0;
     uint32_t h_counters[3] = {0, 0, 0}, h_R = 0;
@@ -112,6 +110,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
     const int64_t R = h_R;
+    if (R > 0x7FFFFFFFll) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^31-1 tile instances in one view");
     g_stats.num_rendered = R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
     if (num_rendered) *num_rendered = R;
@@ -179,7 +178,6 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 #undef LAUNCH_FWD
     }
     KCHECK("lg_blend_fwd");
-    (void)HW;
     if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
         ProfScope ps(prof, "score", stream);
         lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
