@@ -51,6 +51,8 @@ enum {
                               canonical path to ~1e-6, far inside the 1e-4 contract; never used for count renders,
                               whose integer outputs are bit-pinned */
     LG_FLAG_PROFILE = 4,   /* record per-kernel hipEvent timings, read back with lg_profile_read() */
+    LG_FLAG_SKIP_COLOR = 16, /* significance-only forward: K1 does not read the SH rows (colours = 0, the image is meaningless);
+                              counts, scores and radii are unaffected.  Used by the sharded prune pass, which discards the image. */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc

@@ -85,7 +85,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "preprocess", stream);
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
     lg_preprocess<RAWP, DIR><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,      \
-                                                                      v->scale_modifier, v->prefiltered, v->viewmatrix, v->projmatrix, \
+                                                                      v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
             // rows that are whole float4s and 16-byte aligned are read directly (no LDS); anything else is staged through LDS

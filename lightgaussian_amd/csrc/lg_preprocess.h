@@ -41,7 +41,7 @@ __device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + exp
 
 template <bool RAW, bool DIRECT>
 __global__ void __launch_bounds__(LG_PP)
-lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
+lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int skip_color,
               const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
               const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
               const float* __restrict__ colors_precomp,
@@ -90,7 +90,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;        // dc and rest are separate tensors
     const int rowf = split ? 3 * (M - 1) : 3 * M;          // floats per LDS-staged row
-    if (!DIRECT && shs && vmask && rowf > 0) {
+    if (!DIRECT && !skip_color && shs && vmask && rowf > 0) {
         stage_sh_rows(split ? shs_rest : shs, i0, min(LG_PP, N - i0), rowf, vmask, sh_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -102,9 +102,11 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
         if (vis) {
             radius = sp.radius;
             touched = (uint32_t)((sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0));
-            float rgb[3];
+            float rgb[3] = {0.0f, 0.0f, 0.0f};
             uint32_t cb = 0;
-            if (colors_precomp) {
+            if (skip_color) {
+                // significance-only pass (LG_FLAG_SKIP_COLOR): the image is not wanted, so the SH rows are never read
+            } else if (colors_precomp) {
                 rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1]; rgb[2] = colors_precomp[3 * (size_t)i + 2];
             } else {
                 float sh[LG_SH_MAXF];

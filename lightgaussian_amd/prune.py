@@ -113,6 +113,16 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
     """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same
     Gaussians; returns the same (gaussian_list, imp_list) on every rank.  Without an initialised process
     group (or at world size 1, unless force_collectives) it is the single-process loop with frozen getters."""
+    from . import rasterizer
+    prev = rasterizer._OPTIONS["skip_color_in_count"]
+    rasterizer.set_option("skip_color_in_count", True)   # the pass discards the images: do not read 192 B of SH per Gaussian per view
+    try:
+        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives)
+    finally:
+        rasterizer.set_option("skip_color_in_count", prev)
+
+
+def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives):
     if not (dist.is_available() and dist.is_initialized()):
         return prune_list(_FrozenGetters(gaussians), scene, pipe, background, count_fn)
     world = dist.get_world_size(group)

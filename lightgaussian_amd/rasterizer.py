@@ -38,14 +38,16 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # process-wide knobs that are not part of the reference API
-_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False}
+_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False}
 
 
 def set_option(name, value):
     """weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
     fast_exp (default True): hardware exp/rcp in render() -- training renders; set False for the canonical,
               bit-pinned arithmetic.  count renders (f_count=True) ALWAYS use the canonical arithmetic;
-    profile: record per-kernel hipEvent timings (read with _lib.profile_read())."""
+    profile: record per-kernel hipEvent timings (read with _lib.profile_read());
+    skip_color_in_count: count renders do not evaluate colours (image = background-free zeros); for passes that only
+              consume gaussians_count / important_score, e.g. prune_list_sharded."""
     if name not in _OPTIONS:
         raise KeyError(name)
     _OPTIONS[name] = value
@@ -93,6 +95,8 @@ class _Call:
             flags |= _lib.FLAG_FAST_EXP
         if _OPTIONS["profile"]:
             flags |= _lib.FLAG_PROFILE
+        if exact and _OPTIONS["skip_color_in_count"]:
+            flags |= _lib.FLAG_SKIP_COLOR
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
                                  int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags)

@@ -419,3 +419,19 @@ def test_fuzz_count_and_image_parity():
         assert np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32)), tag
         fast = gpu_common.hip_forward_backward(kw, count=False)
         assert np.abs(fast["color"] - ref.color).max() <= 1e-5, tag
+
+
+def test_skip_color_leaves_counts_and_scores_untouched():
+    """LG_FLAG_SKIP_COLOR (significance-only pass): same counts / scores / radii bit for bit, image not evaluated."""
+    import gpu_common
+    from lightgaussian_amd import rasterizer
+    kw = _scene(CASES[0])
+    a = gpu_common.hip_forward_backward(kw, count=True)
+    rasterizer.set_option("skip_color_in_count", True)
+    try:
+        b = gpu_common.hip_forward_backward(kw, count=True)
+        c = gpu_common.hip_forward_backward(kw, count=False)     # render() is never affected
+    finally:
+        rasterizer.set_option("skip_color_in_count", False)
+    assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["score"], b["score"]) and np.array_equal(a["radii"], b["radii"])
+    assert gpu_common.rel_err(c["color"], a["color"]) <= 1e-5
