@@ -73,7 +73,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
     const int N = g->N, W = v->image_width, H = v->image_height;
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
-    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    const int ntiles_pad = (ntiles + 31) / 32 * 32; // grid of the per-tile kernels (xcd_tile needs a multiple of 32)
     GeomView geo = carve_geom(geom_p, N);
     ImgView img = carve_img(img_p, W, H);
     if (binning_out) *binning_out = nullptr;
@@ -167,9 +167,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     }
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
-        dim3 grid(ntiles_pad8), block(256);
+        dim3 grid(ntiles_pad), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
-    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, point_list, geo.rec, v->bg,     \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, point_list, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
@@ -220,7 +220,7 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     const int N = g->N, W = v->image_width, H = v->image_height;
     if (N == 0) return LG_OK;
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
-    const int ntiles_pad8 = (ntiles + 7) / 8 * 8;
+    const int ntiles_pad = (ntiles + 31) / 32 * 32; // grid of the per-tile kernels (xcd_tile needs a multiple of 32)
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
@@ -228,10 +228,10 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
-            lg_blend_bwd<false><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<false><<<ntiles_pad, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, rows);
         else
-            lg_blend_bwd<true><<<ntiles_pad8, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad8, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<true><<<ntiles_pad, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                 img.final_T, img.n_contrib, dL_dcolor, rows);
     }
     KCHECK("lg_blend_bwd");
