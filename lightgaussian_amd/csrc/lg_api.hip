@@ -73,7 +73,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
     const int N = g->N, W = v->image_width, H = v->image_height;
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
-    const int ntiles_pad = (ntiles + 31) / 32 * 32; // grid of the per-tile kernels (xcd_tile needs a multiple of 32)
+    const int ntiles_pad = (ntiles + LG_TILE_GRID_ALIGN - 1) / LG_TILE_GRID_ALIGN * LG_TILE_GRID_ALIGN; // grid of the per-tile kernels
     GeomView geo = carve_geom(geom_p, N);
     ImgView img = carve_img(img_p, W, H);
     if (binning_out) *binning_out = nullptr;
@@ -220,7 +220,7 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     const int N = g->N, W = v->image_width, H = v->image_height;
     if (N == 0) return LG_OK;
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
-    const int ntiles_pad = (ntiles + 31) / 32 * 32; // grid of the per-tile kernels (xcd_tile needs a multiple of 32)
+    const int ntiles_pad = (ntiles + LG_TILE_GRID_ALIGN - 1) / LG_TILE_GRID_ALIGN * LG_TILE_GRID_ALIGN; // grid of the per-tile kernels
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used

@@ -10,13 +10,18 @@
 // Neighbouring tiles share Gaussians, so each XCD (own 4 MB L2) is given runs of 4 consecutive tiles -- but runs from
 // all over the image, interleaved with the other XCDs.  (Giving each XCD one contiguous eighth of the image, the first
 // design, was measured 15 % SLOWER on both blend kernels than no remapping at all: work per image band is uneven, and
-// a static band per XCD turns that into idle XCDs.  Interleaved runs of 4: 3 % faster than no remapping.)
+// a static band per XCD turns that into idle XCDs.  Interleaved runs of 1, 2, 4, 8 or 32 tiles all measure the same
+// within noise -- these kernels are VALU-bound, the L2 affinity buys nothing measurable; runs of 4 are kept.)
 // The map is a bijection on [0, ntiles_pad) for ntiles_pad a multiple of 32; callers guard tile < ntiles.
+#ifndef LG_XCD_RUN_LOG2
+#define LG_XCD_RUN_LOG2 2 // runs of 4 consecutive tiles per XCD
+#endif
+#define LG_TILE_GRID_ALIGN (8 << LG_XCD_RUN_LOG2)
 __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad)
 {
     (void)ntiles_pad;
     const int r = b >> 3; // index of this workgroup inside its XCD's stream
-    return ((r >> 2) << 5) + ((b & 7) << 2) + (r & 3); // XCD x owns tiles 32g + 4x .. 32g + 4x + 3 of every group g of 32 tiles
+    return ((r >> LG_XCD_RUN_LOG2) << (LG_XCD_RUN_LOG2 + 3)) + ((b & 7) << LG_XCD_RUN_LOG2) + (r & ((1 << LG_XCD_RUN_LOG2) - 1));
 }
 
 #define LG_Q 64 // LDS queue depth per wave = one batch
