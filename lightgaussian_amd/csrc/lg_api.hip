@@ -161,6 +161,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_finalize_bins");
     }
+    {
+        ProfScope ps(prof, "tile_order", stream);
+        lg_tile_order<<<1, 1024, 0, stream>>>(ntiles, bin.ranges, bin.tile_order);
+    }
+    KCHECK("lg_tile_order");
     if (count && N > 0) {
         HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
         HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
@@ -228,10 +233,10 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
-            lg_blend_bwd<false><<<ntiles_pad, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<false><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, rows);
         else
-            lg_blend_bwd<true><<<ntiles_pad, 64, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<true><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
                                                                 img.final_T, img.n_contrib, dL_dcolor, rows);
     }
     KCHECK("lg_blend_bwd");

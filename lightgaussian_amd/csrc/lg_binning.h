@@ -90,3 +90,30 @@ lg_finalize_bins(uint32_t R, int gx, int depth_bits, int gid_bits, const uint64_
     if (i == R - 1) ranges[t].y = R;
 }
 
+
+// Longest-processing-time-first dispatch order of the per-tile kernels.  The backward runs ONE wave per tile and only
+// ~1.6 tiles per wave slot, so which tiles share a slot decides the makespan: handing out the long lists first lets
+// the short ones fill the gaps.  Counting sort of the tiles by list length (256 buckets of 16 entries, longest first);
+// the order inside a bucket is arbitrary, which is harmless because tiles are independent.
+__global__ void __launch_bounds__(1024)
+lg_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[256], base[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int t = (int)tid; t < T; t += 1024) {
+        const uint2 r = ranges[t];
+        atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u); // bucket 0 = longest
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int t = (int)tid; t < T; t += 1024) {
+        const uint2 r = ranges[t];
+        order[atomicAdd(&base[255u - min((r.y - r.x) >> 4, 255u)], 1u)] = (uint32_t)t;
+    }
+}

@@ -299,15 +299,15 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-lg_blend_bwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
+lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_sorted, const float4* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dpix, float* __restrict__ part)
 {
     __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
-    const int tile = xcd_tile(blockIdx.x, ntiles_pad);
-    if (tile >= ntiles) return;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int tile = (int)tile_order[blockIdx.x]; // longest lists first (lg_tile_order)
     const uint32_t lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const uint2 range = ranges[tile];

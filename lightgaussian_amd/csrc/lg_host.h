@@ -122,6 +122,7 @@ static ImgView carve_img(void* base, int W, int H)
 // offsets for both key formats.
 struct BinView {
     uint2* ranges;                  // [tiles]
+    uint32_t* tile_order;           // [tiles] tile indices, longest list first (dispatch order of the per-tile kernels)
     uint32_t* point_list;           // [R] Gaussian ids in (tile, depth, id) order
     uint32_t* slot_out;             // [R] pre-sort slot of every sorted position (row address of the backward)
     uint64_t *keys_in, *keys_out;   // [R] radix-sort double buffer
@@ -142,6 +143,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     size_t n = (size_t)(R > 0 ? R : 1);
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
+    v.tile_order = (uint32_t*)take((size_t)gx * gy * 4);
     v.point_list = (uint32_t*)take(n * 4);
     v.slot_out = (uint32_t*)take(n * 4);
     v.keys_in = (uint64_t*)take(n * 8);
