@@ -174,7 +174,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         dim3 grid(ntiles_pad), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
-    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, point_list, geo.rec, v->bg,     \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.tile_order, bin.ranges, point_list, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }

@@ -70,14 +70,19 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
 // K6 / K6c: forward blend
 template <bool COUNT, bool FSCORE, bool EXACT>
 __global__ void __launch_bounds__(256)
-lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
+lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+#ifdef LG_FWD_LPT // longest-list-first like the backward: measured 0.292 vs 0.298 ms (noise) with 4 waves per tile -- off
+    if ((int)blockIdx.x >= ntiles) return;
+    const int tile = (int)tile_order[blockIdx.x];
+#else
     const int tile = xcd_tile(blockIdx.x, ntiles_pad);
     if (tile >= ntiles) return;
+#endif
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -99,7 +104,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         float4 r0, r1, r2;
         if (idx < range.y) {
             const uint32_t id = point_list[idx];
-            r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+            r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
             // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
             hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
         }
@@ -354,7 +359,7 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
             float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
             if (lane < nb) {
                 const uint32_t id = point_list[base + lane];
-                r0 = rec[3 * (size_t)id]; r1 = rec[3 * (size_t)id + 1]; r2 = rec[3 * (size_t)id + 2];
+                r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
                 uint32_t m = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {

@@ -129,9 +129,9 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 }
                 lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
             }
-            g.rec[3 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
-            g.rec[3 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
-            g.rec[3 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
+            g.rec[LG_REC_F4 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
+            g.rec[LG_REC_F4 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
+            g.rec[LG_REC_F4 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
             g.aux[2 * (size_t)i + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
             g.aux[2 * (size_t)i + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
             g.tinfo[i] = make_uint4((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16),
