@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--scale", type=float, default=0.004, help="median world-space sigma of the synthetic Gaussians (frozen workload: 0.004)")
     ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
     ap.add_argument("--fused", action="store_true", help="render_fused (SURVEY 8f row 1 extension): getters inside the kernels")
+    ap.add_argument("--loss", choices=["l1", "l1_dssim", "l1_dssim_torch"], default="l1",
+                    help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
+                         "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-n", type=int, default=0, help="Gaussians in the CPU sample (0 = same as workload)")
@@ -71,6 +74,8 @@ def algorithmic_bytes(N, V, R, P, M):
         "score": 12 * N,
         "blend_bwd": 88 * R + 20 * P,
         "preprocess_bwd": (108 + 12 * M) * V + (56 + 12 * M) * N + 52 * R,
+        "loss_fwd": 3 * P * (8 + 12),   # read image + gt, write the three partial-derivative maps (per channel-pixel)
+        "loss_bwd": 3 * P * (12 + 8 + 4),
     }
 
 
@@ -129,6 +134,26 @@ def main():
         student = parallel.make_student(pc, max(args.sh_degree - 1, 0)).requires_grad_(True)
         sparams = [student._xyz, student._features_dc, student._features_rest, student._scaling, student._rotation, student._opacity]
 
+    def torch_ssim(img1, img2):
+        """The reference's SSIM as it runs there (utils/loss_utils.py:46-85: five grouped conv2d + elementwise torch ops);
+        timing comparison for --loss l1_dssim_torch only."""
+        g = torch.tensor([math.exp(-((x - 5) ** 2) / 4.5) for x in range(11)])
+        g = (g / g.sum()).unsqueeze(1)
+        window = (g @ g.t()).expand(3, 1, 11, 11).contiguous().to(img1.device)
+        conv = lambda t: torch.nn.functional.conv2d(t, window, padding=5, groups=3)
+        mu1, mu2 = conv(img1), conv(img2)
+        mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+        s1, s2, s12 = conv(img1 * img1) - mu1_sq, conv(img2 * img2) - mu2_sq, conv(img1 * img2) - mu1_mu2
+        return (((2 * mu1_mu2 + 0.0001) * (2 * s12 + 0.0009)) / ((mu1_sq + mu2_sq + 0.0001) * (s1 + s2 + 0.0009))).mean()
+
+    def photometric(image, gt):
+        if args.loss == "l1":
+            return (image - gt).abs().mean()
+        if args.loss == "l1_dssim":
+            from lightgaussian_amd import loss_utils
+            return loss_utils.l1_dssim_loss(image, gt, 0.2)[0]
+        return 0.8 * (image - gt).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt))
+
     def step(i):
         k = my_views[i % len(my_views)]
         if args.mode == "fwdbwd":
@@ -137,7 +162,7 @@ def main():
             for p in params:
                 p.grad = None
             pkg = render(cams[k], pc, pipe, bg)
-            loss = (pkg["render"] - gts[k]).abs().mean()
+            loss = photometric(pkg["render"], gts[k])
             loss.backward()
         elif args.mode == "fwd":
             with torch.no_grad():
@@ -209,6 +234,8 @@ def main():
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
                        "getters": "fused into K1/K9 (render_fused, SURVEY 8f-1 extension)" if args.fused else "torch (reference render() call pattern)",
+                       "loss": {"l1": "L1 (torch)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
+                                "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
                        "parallelism": f"camera-shard x{world}"},
         }
         result.update(extra)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 2
+#define LG_ABI_VERSION 3
 
 enum {
     LG_OK = 0,
@@ -139,6 +139,22 @@ int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii
 /* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
  * prune pass to rebuild per-view scores from integer counts. */
 int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream);
+
+/* --- photometric loss of the training step -------------------------------------
+ * Replaces utils/loss_utils.py:18-19 l1_loss() and :46-85 ssim() (11x11 Gaussian window sigma 1.5 of :26-43,
+ * conv2d zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W), as combined at prune_finetune.py:161-164:
+ *     loss = (1 - lambda) * l1 + lambda * (1 - ssim).
+ * img, gt: [C,H,W] fp32 device.  state: lg_loss_state_bytes(C,H,W) device bytes, written by forward, read by backward.
+ * out_l1_ssim: device float[2] = {mean |img-gt|, mean ssim_map}.
+ * backward: dL_dimg [C,H,W] = scale_l1 * *dL_dl1 * d l1/d img + scale_ssim * *dL_dssim * d ssim/d img; dL_dl1 / dL_dssim are
+ * DEVICE scalars (the autograd gradients; NULL => that term is 0), so the call never synchronises.
+ * flags: LG_FLAG_DEBUG, LG_FLAG_PROFILE. */
+size_t lg_loss_state_bytes(int32_t C, int32_t H, int32_t W);
+int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, void* state, float* out_l1_ssim,
+                    uint32_t flags, void* stream);
+int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const void* state,
+                     const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
+                     uint32_t flags, void* stream);
 
 /* diagnostics: the packed wave reduction used by the backward blend, on one wave: in [64][9] -> out [9] */
 int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream);

@@ -22,7 +22,8 @@ FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR = 1, 2
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
-           "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9"]
+           "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9", "lg_loss_state_bytes",
+           "lg_loss_forward", "lg_loss_backward"]
 
 
 class lg_view(C.Structure):
@@ -84,6 +85,11 @@ def load():
     lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 9 + [vp, vp]
     lib.lg_score_from_count.restype = C.c_int
     lib.lg_score_from_count.argtypes = [C.c_int32, vp, vp, vp, vp]
+    lib.lg_loss_state_bytes.restype = C.c_size_t; lib.lg_loss_state_bytes.argtypes = [C.c_int32] * 3
+    lib.lg_loss_forward.restype = C.c_int
+    lib.lg_loss_forward.argtypes = [C.c_int32] * 3 + [vp, vp, vp, vp, C.c_uint32, vp]
+    lib.lg_loss_backward.restype = C.c_int
+    lib.lg_loss_backward.argtypes = [C.c_int32] * 3 + [vp, vp, vp, vp, C.c_float, vp, C.c_float, vp, C.c_uint32, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []

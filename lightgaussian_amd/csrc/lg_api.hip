@@ -5,6 +5,7 @@
 //   lg_wave.h        wave64 primitives (DPP / permlane reductions)
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
 //   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_finalize_bins   (per instance; K2/K4 = rocPRIM scan / radix sort)
+//   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_blend.h       K6 lg_blend_fwd<COUNT,FSCORE,EXACT>, lg_score_kernel, K7 lg_blend_bwd<EXACT>   (per tile, VALU-bound)
 //
 // Pipeline of one view:
@@ -19,6 +20,7 @@
 #include "lg_preprocess.h"
 #include "lg_binning.h"
 #include "lg_blend.h"
+#include "lg_loss.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -263,6 +265,52 @@ extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float*
     lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_score_kernel launch", e);
+    return LG_OK;
+}
+
+extern "C" size_t lg_loss_state_bytes(int32_t C, int32_t H, int32_t W)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    return carve_loss(nullptr, C, H, W).total;
+}
+
+extern "C" int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, void* state, float* out_l1_ssim,
+                               uint32_t flags, void* stream_p)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || C > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "bad image shape");
+    if (!img || !gt || !state || !out_l1_ssim) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
+    LossView lv = carve_loss(state, C, H, W);
+    dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
+    if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    {
+        ProfScope ps(prof, "loss_fwd", stream);
+        lg_loss_fwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, lv.partials);
+        KCHECK("lg_loss_fwd");
+        lg_loss_finalize<<<1, 256, 0, stream>>>((int)(grid.x * grid.y * grid.z), 1.0 / ((double)C * H * W), lv.partials, out_l1_ssim);
+        KCHECK("lg_loss_finalize");
+    }
+    return LG_OK;
+}
+
+extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const void* state,
+                                const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
+                                uint32_t flags, void* stream_p)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || C > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "bad image shape");
+    if (!img || !gt || !state || !dL_dimg) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
+    LossView lv = carve_loss(const_cast<void*>(state), C, H, W);
+    dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
+    if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    {
+        ProfScope ps(prof, "loss_bwd", stream);
+        lg_loss_bwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, dL_dl1, scale_l1, dL_dssim, scale_ssim,
+                                              (float)(1.0 / ((double)C * H * W)), dL_dimg);
+        KCHECK("lg_loss_bwd");
+    }
     return LG_OK;
 }
 
