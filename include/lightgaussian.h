@@ -130,6 +130,8 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  *   dL_dmeans3D [N,3]  dL_dshs [N,M,3]  dL_dcolors [N,3]  dL_dopacity [N,1]
  *   dL_dscales [N,3]   dL_drotations [N,4]  dL_dcov3D [N,6]  dL_dshs_rest [N,M-1,3] (RAW_PARAMS only, else NULL)
  *   scratch: lg_backward_scratch_bytes(N, num_rendered)
+ * geom / img are read-only here; inside `binning` lg_backward fills one reserved array (the dispatch order of its
+ * per-tile kernel) -- idempotent, so retain_graph-style repeated backward calls on the same saved state are fine.
  */
 int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii, const void* geom, const void* binning,
                 const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
@@ -139,6 +141,18 @@ int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii
 /* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
  * prune pass to rebuild per-view scores from integer counts. */
 int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream);
+
+/* --- prune epilogue -------------------------------------------------------------
+ * Replaces prune.py:112-128 calculate_v_imp_score() followed by the mask of scene/gaussian_model.py:776-782
+ * prune_gaussians(), entirely on the device (two radix selects instead of two sorts + host indexing; no synchronisation):
+ *   volume = (s0*s1)*s2 of the ACTIVATED scaling [N,3]; kth = element int(N*0.9) of its DESCENDING sort;
+ *   v_list[i] = powf(volume[i] / kth, v_pow) * imp_list[i];
+ *   thr = element int(prune_percent*(N-1)) of v_list's ASCENDING sort;  mask[i] = v_list[i] <= thr  (ties pruned).
+ * v_list [N] float, mask [N] uint8 (1 = prune), thresholds: device float[2] = {kth, thr};
+ * scratch: lg_prune_scratch_bytes(N) device bytes.  N == 0 is an error (the reference raises IndexError). */
+size_t lg_prune_scratch_bytes(int32_t N);
+int lg_prune_epilogue(int32_t N, const float* scaling, const float* imp_list, float v_pow, double prune_percent,
+                      float* v_list, uint8_t* mask, float* thresholds, void* scratch, uint32_t flags, void* stream);
 
 /* --- photometric loss of the training step -------------------------------------
  * Replaces utils/loss_utils.py:18-19 l1_loss() and :46-85 ssim() (11x11 Gaussian window sigma 1.5 of :26-43,

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblightgaussian_hip.so")
+# LIGHTGAUSSIAN_HIP_LIB: A/B builds of the same library on one GPU box (tools/gpu_ab.sh); always an in-tree HIP build
+LIB_PATH = os.environ.get("LIGHTGAUSSIAN_HIP_LIB") or os.path.join(_HERE, "liblightgaussian_hip.so")
 
 LG_OK = 0
 LG_ERR_INVALID_ARGUMENT = -1
@@ -23,7 +24,7 @@ FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR = 1, 2
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
            "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9", "lg_loss_state_bytes",
-           "lg_loss_forward", "lg_loss_backward"]
+           "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue"]
 
 
 class lg_view(C.Structure):
@@ -90,6 +91,9 @@ def load():
     lib.lg_loss_forward.argtypes = [C.c_int32] * 3 + [vp, vp, vp, vp, C.c_uint32, vp]
     lib.lg_loss_backward.restype = C.c_int
     lib.lg_loss_backward.argtypes = [C.c_int32] * 3 + [vp, vp, vp, vp, C.c_float, vp, C.c_float, vp, C.c_uint32, vp]
+    lib.lg_prune_scratch_bytes.restype = C.c_size_t; lib.lg_prune_scratch_bytes.argtypes = [C.c_int32]
+    lib.lg_prune_epilogue.restype = C.c_int
+    lib.lg_prune_epilogue.argtypes = [C.c_int32, vp, vp, C.c_float, C.c_double, vp, vp, vp, vp, C.c_uint32, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []

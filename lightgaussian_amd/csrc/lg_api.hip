@@ -6,6 +6,7 @@
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
 //   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_finalize_bins   (per instance; K2/K4 = rocPRIM scan / radix sort)
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
+//   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_blend.h       K6 lg_blend_fwd<COUNT,FSCORE,EXACT>, lg_score_kernel, K7 lg_blend_bwd<EXACT>   (per tile, VALU-bound)
 //
 // Pipeline of one view:
@@ -21,6 +22,7 @@
 #include "lg_binning.h"
 #include "lg_blend.h"
 #include "lg_loss.h"
+#include "lg_prune.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -163,11 +165,6 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_finalize_bins");
     }
-    {
-        ProfScope ps(prof, "tile_order", stream);
-        lg_tile_order<<<1, 1024, 0, stream>>>(ntiles, bin.ranges, bin.tile_order);
-    }
-    KCHECK("lg_tile_order");
     if (count && N > 0) {
         HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
         HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
@@ -176,7 +173,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         dim3 grid(ntiles_pad), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
-    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.tile_order, bin.ranges, point_list, geo.rec, v->bg,     \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, point_list, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
@@ -233,6 +230,14 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     if (R > 0) {
+        // dispatch order of the per-tile backward (longest lists first).  Computed here, not in the forward, so that
+        // forward-only renders and the significance pass do not pay for it; it lands in the array reserved for it inside
+        // the binning buffer (the one write the backward makes to saved state; idempotent).
+        ProfScope ps(prof, "tile_order", stream);
+        lg_tile_order<<<1, 1024, 0, stream>>>(ntiles, bin.ranges, bin.tile_order);
+    }
+    KCHECK("lg_tile_order");
+    if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
             lg_blend_bwd<false><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
@@ -265,6 +270,44 @@ extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float*
     lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_score_kernel launch", e);
+    return LG_OK;
+}
+
+extern "C" size_t lg_prune_scratch_bytes(int32_t N)
+{
+    (void)N;
+    return align_up(2 * sizeof(LgSelect));
+}
+
+extern "C" int lg_prune_epilogue(int32_t N, const float* scaling, const float* imp_list, float v_pow, double prune_percent,
+                                 float* v_list, uint8_t* mask, float* thresholds, void* scratch, uint32_t flags, void* stream_p)
+{
+    if (N <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "prune epilogue needs N >= 1 (the reference indexes an empty sort)");
+    if (!scaling || !imp_list || !v_list || !mask || !thresholds || !scratch) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    if (!(prune_percent >= 0.0 && prune_percent <= 1.0)) return fail(LG_ERR_INVALID_ARGUMENT, "prune_percent must be in [0, 1]");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
+    LgSelect* st = (LgSelect*)scratch;
+    // prune.py:122-124: element `index = int(N * 0.9)` of the DESCENDING sort = ascending rank N - 1 - index
+    const int index = (int)((double)N * 0.9);
+    const uint32_t rank_volume = (uint32_t)(N - 1 - (index < N ? index : N - 1));
+    // scene/gaussian_model.py:778-779: ascending index int(percent * (N - 1)), evaluated like Python (double)
+    const uint32_t rank_score = (uint32_t)(prune_percent * (double)(N - 1));
+    const int blocks = (int)std::min<int64_t>(((int64_t)N + 255) / 256, 2048);
+    ProfScope ps(prof, "prune_epilogue", stream);
+    HIP_TRY(hipMemsetAsync(st, 0, 2 * sizeof(LgSelect), stream));
+    for (int p = 0; p < 4; p++) {
+        lg_select_pass<0><<<blocks, 256, 0, stream>>>(N, p, rank_volume, scaling, &st[0]);
+        KCHECK("lg_select_pass<volume>");
+    }
+    lg_v_imp_score_kernel<<<blocks, 256, 0, stream>>>(N, rank_volume, scaling, imp_list, v_pow, &st[0], v_list, &st[1], thresholds);
+    KCHECK("lg_v_imp_score_kernel");
+    for (int p = 1; p < 4; p++) {
+        lg_select_pass<1><<<blocks, 256, 0, stream>>>(N, p, rank_score, v_list, &st[1]);
+        KCHECK("lg_select_pass<score>");
+    }
+    lg_prune_mask_kernel<<<blocks, 256, 0, stream>>>(N, rank_score, v_list, &st[1], mask, thresholds);
+    KCHECK("lg_prune_mask_kernel");
     return LG_OK;
 }
 

@@ -70,19 +70,16 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
 // K6 / K6c: forward blend
 template <bool COUNT, bool FSCORE, bool EXACT>
 __global__ void __launch_bounds__(256)
-lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
-#ifdef LG_FWD_LPT // longest-list-first like the backward: measured 0.292 vs 0.298 ms (noise) with 4 waves per tile -- off
-    if ((int)blockIdx.x >= ntiles) return;
-    const int tile = (int)tile_order[blockIdx.x];
-#else
+    // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
+    // already give 4 rounds of wave slots; the XCD-interleaved static map stays)
     const int tile = xcd_tile(blockIdx.x, ntiles_pad);
     if (tile >= ntiles) return;
-#endif
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;

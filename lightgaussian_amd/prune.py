@@ -61,6 +61,35 @@ def prune_mask_select(percent, import_score):
     return (import_score <= value_nth_percentile).squeeze()
 
 
+def prune_epilogue(gaussians, imp_list, v_pow, percent):
+    """calculate_v_imp_score (prune.py:112-128) + the mask of prune_gaussians (scene/gaussian_model.py:776-782) in one
+    device-resident pass of the HIP library (lg_prune_epilogue: two radix selects, no sort, no host read-back).
+    Returns (v_list [N] float32, mask [N] bool, thresholds [2] = {kth volume, score threshold}); same values as
+    calculate_v_imp_score(...) / prune_mask(percent, v_list).  CUDA/HIP tensors only -- no fallback."""
+    import ctypes as C
+    from . import _lib
+    from . import rasterizer
+    with torch.no_grad():
+        scaling = gaussians.get_scaling.detach().contiguous().float()
+        imp = imp_list.detach().reshape(-1).contiguous().float()
+    if not (scaling.is_cuda and imp.is_cuda):
+        raise RuntimeError("prune_epilogue runs on the MI355X HIP library only (no CPU fallback)")
+    N = scaling.shape[0]
+    if imp.shape[0] != N:
+        raise ValueError(f"imp_list has {imp.shape[0]} entries for {N} Gaussians")
+    lib = _lib.load()
+    dev = scaling.device
+    v_list = torch.empty(N, dtype=torch.float32, device=dev)
+    mask = torch.empty(N, dtype=torch.uint8, device=dev)
+    thresholds = torch.empty(2, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.lg_prune_scratch_bytes(N), dtype=torch.uint8, device=dev)
+    flags = _lib.FLAG_PROFILE if rasterizer._OPTIONS["profile"] else 0
+    _lib.check(lib.lg_prune_epilogue(N, scaling.data_ptr(), imp.data_ptr(), float(v_pow), float(percent), v_list.data_ptr(),
+                                     mask.data_ptr(), thresholds.data_ptr(), scratch.data_ptr(), flags,
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return v_list, mask.bool(), thresholds
+
+
 class _FrozenGetters:
     """The Gaussians do not change during a significance pass, so the activations and the cat() of
     GaussianModel's getters (scene/gaussian_model.py:98-118) are evaluated ONCE instead of once per view
