@@ -201,6 +201,23 @@ def main():
         elapsed = time.perf_counter() - t0
         extra["significance_pass"] = {"views": args.steps * world, "seconds": round(elapsed, 4),
                                       "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item())}
+        if rank == 0:
+            # the epilogue of config C4 (untimed w.r.t. `value`): calculate_v_imp_score(v_pow=0.1) + prune mask at 66 %,
+            # device-resident radix selects (lg_prune_epilogue) next to the reference's torch formulation (2 sorts)
+            from lightgaussian_amd import prune as _prune
+            def timed(fn, reps=5):
+                fn(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    out = fn()
+                b.record(); torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps, out
+            with torch.no_grad():
+                ms_hip, (v_hip, m_hip, _) = timed(lambda: _prune.prune_epilogue(pc, imp, 0.1, 0.66))
+                ms_torch, m_torch = timed(lambda: _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1)))
+            extra["significance_pass"]["epilogue"] = {"hip_ms": round(ms_hip, 4), "torch_ms": round(ms_torch, 4), "pruned": int(m_hip.sum().item()),
+                                                      "mask_disagreements_vs_torch": int((m_hip != m_torch).sum().item())}
     else:
         for i in range(args.warmup):
             step(i)

@@ -39,6 +39,7 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
 // [N,M-1,3] -- and the activations (scene/gaussian_model.py:98-118) are evaluated here instead of by torch.
 __device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// 92 VGPRs -> 5 waves/SIMD.  Forcing 6 or 8 (amdgpu_waves_per_eu) spills 43 / 71 registers: measured 0.22 -> 0.28 / 0.45 ms.
 template <bool RAW, bool DIRECT>
 __global__ void __launch_bounds__(LG_PP)
 lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int skip_color,
@@ -51,6 +52,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     // DIRECT: every visible lane reads its own 16-byte-aligned SH row with float4 loads and no LDS is allocated
     // (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3); otherwise rows go through LDS.
     __shared__ __attribute__((aligned(16))) float sh_rows[DIRECT ? 4 : LG_PP * LG_SH_MAXF];
+    __shared__ float4 st_rec[LG_PP * 3], st_aux[LG_PP * 2]; // records leave through LDS as coalesced 16-byte stores
+    static_assert(LG_REC_F4 == 3, "coalesced record store assumes packed 48-byte records");
     const uint32_t lane = threadIdx.x;
     const int i0 = blockIdx.x * LG_PP;
     const int i = i0 + (int)lane;
@@ -64,7 +67,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     LgSplat sp;
     if (i < N) {
         px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2];
-        // near-plane test first so culled Gaussians cost 12 bytes of reads
+        // near-plane test first so culled Gaussians cost 12 bytes of reads (hoisting the scale / rotation / opacity loads
+        // above this branch was measured: no change)
         const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
         if (vz > 0.2f) {
             if (cov3D_precomp) {
@@ -129,16 +133,31 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 }
                 lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
             }
-            g.rec[LG_REC_F4 * (size_t)i + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
-            g.rec[LG_REC_F4 * (size_t)i + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
-            g.rec[LG_REC_F4 * (size_t)i + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
-            g.aux[2 * (size_t)i + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
-            g.aux[2 * (size_t)i + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
+            st_rec[3 * lane + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
+            st_rec[3 * lane + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
+            st_rec[3 * lane + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
+            st_aux[2 * lane + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
+            st_aux[2 * lane + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
             g.tinfo[i] = make_uint4((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16),
                                     __float_as_uint(sp.depth), 0u);
         }
         radii[i] = radius;
         g.touched[i] = touched;
+    }
+    // The records of the workgroup's 64 Gaussians are contiguous in rec / aux: staged in LDS and written as coalesced
+    // 16-byte stores (per-lane 48-byte-stride stores measured 0.26 -> 0.22 ms for the whole kernel).  Entries of
+    // invisible Gaussians carry stale LDS contents; nothing reads them (touched == 0).
+    if (vmask) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nrec = min(LG_PP, N - i0);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if ((int)(k * LG_PP + lane) < 3 * nrec) g.rec[3 * (size_t)i0 + k * LG_PP + lane] = st_rec[k * LG_PP + lane];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if ((int)(k * LG_PP + lane) < 2 * nrec) g.aux[2 * (size_t)i0 + k * LG_PP + lane] = st_aux[k * LG_PP + lane];
     }
     // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
     // largest depth of the workgroup (bit pattern; positive floats order like integers), for the packed sort key.
@@ -325,6 +344,8 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
             }
         }
     }
+    // (staging the [N,3] gradients through LDS for lane-contiguous stores, as K1 does for its records, was measured:
+    // 0.366 -> 0.370 ms, no gain -- this kernel already runs at ~4.4 TB/s of algorithmic traffic)
     if (i >= N) return;
     dL_dmeans2D[3 * (size_t)i] = m2[0]; dL_dmeans2D[3 * (size_t)i + 1] = m2[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.0f;
     dL_dmeans3D[3 * (size_t)i] = m3[0]; dL_dmeans3D[3 * (size_t)i + 1] = m3[1]; dL_dmeans3D[3 * (size_t)i + 2] = m3[2];
