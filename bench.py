@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--scale", type=float, default=0.004, help="median world-space sigma of the synthetic Gaussians (frozen workload: 0.004)")
     ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
-    ap.add_argument("--fused", action="store_true", help="render_fused (SURVEY 8f row 1 extension): getters inside the kernels")
+    ap.add_argument("--no-fuse", action="store_true", help="force the reference's literal getter pattern (torch exp/sigmoid/normalize/cat "
+                    "per render call); default: render() evaluates the getters of a reference GaussianModel inside the kernels")
+    ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)  # former opt-in flag; now the default behaviour of render()
     ap.add_argument("--loss", choices=["l1", "l1_dssim", "l1_dssim_torch"], default="l1",
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
@@ -98,8 +100,7 @@ def main():
     from lightgaussian_amd import _lib, synthetic as syn
     from lightgaussian_amd import rasterizer
     from lightgaussian_amd.gaussian_renderer import render, count_render, render_fused
-    if args.fused:
-        render = render_fused
+    rasterizer.set_option("fuse_getters", not args.no_fuse)
     from lightgaussian_amd.prune import prune_list_sharded
 
     _lib.load()
@@ -250,7 +251,8 @@ def main():
                                    f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
-                       "getters": "fused into K1/K9 (render_fused, SURVEY 8f-1 extension)" if args.fused else "torch (reference render() call pattern)",
+                       "getters": "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
+                                  "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
                        "loss": {"l1": "L1 (torch)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
                        "parallelism": f"camera-shard x{world}"},
@@ -293,6 +295,22 @@ def main():
         result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
         tot_bytes = sum(ab[k] * per_kernel[k]["launches_per_step"] for k in per_kernel if k in ab)
         result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
+
+    # ---- the same step with the reference's literal getter pattern (torch exp/sigmoid/normalize/cat per call), untimed leg ----
+    if rank == 0 and not args.no_fuse and args.mode in ("fwdbwd", "fwd", "distill"):
+        rasterizer.set_option("fuse_getters", False)
+        nlit = max(5, min(30, args.steps))
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nlit):
+            step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nlit
+        rasterizer.set_option("fuse_getters", True)
+        result["literal_getter_pattern"] = {"views_per_s_per_gpu": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 4), "steps": nlit,
+                                            "note": "set_option('fuse_getters', False): getters evaluated by torch on every render call, as the reference does"}
 
     # ---- cpu_baseline leg: the oracle on the host cores, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

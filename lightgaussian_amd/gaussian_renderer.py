@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import rasterizer as _rasterizer
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 from .sh_utils import eval_sh
 
@@ -70,8 +71,36 @@ def _screenspace_points(pc):
     return screenspace_points
 
 
+_RAW_FIELDS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _has_reference_getters(pc):
+    """True when `pc` is a GaussianModel whose getters are exactly the reference's (scene/gaussian_model.py:36-47 and
+    :98-118: get_scaling = torch.exp(_scaling), get_opacity = torch.sigmoid(_opacity), get_rotation =
+    F.normalize(_rotation), get_features = cat(_features_dc, _features_rest)) -- identified by the activation attributes
+    setup_functions() installs.  Anything else (frozen getters, custom activations, foreign models) is not touched."""
+    if not all(hasattr(pc, n) for n in _RAW_FIELDS):
+        return False
+    return (getattr(pc, "scaling_activation", None) is torch.exp and getattr(pc, "opacity_activation", None) is torch.sigmoid
+            and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize
+            and pc._features_rest.dim() == 3 and pc._features_dc.dim() == 3 and pc._features_dc.shape[1] == 1)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
-    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    """Render the scene.  Background tensor (bg_color) must be on the GPU.
+
+    With option fuse_getters (default True) and a GaussianModel carrying the reference's own activations, the getters
+    are evaluated INSIDE the kernels from the raw parameters (render_fused: no torch.cat of the SH tensors, no
+    activation kernels; same values to ~1e-7, gradients land on the raw parameters exactly as autograd would route
+    them).  set_option("fuse_getters", False) restores the reference's literal call pattern."""
+    if (_rasterizer._OPTIONS["fuse_getters"] and override_color is None and not pipe.convert_SHs_python
+            and not pipe.compute_cov3D_python and _has_reference_getters(pc)):
+        return render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+    return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+
+
+def _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """gaussian_renderer/__init__.py:22-124 literally: getters in torch, activated tensors into the rasterizer."""
     screenspace_points = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False))
     means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp = _inputs(
@@ -103,7 +132,7 @@ def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mod
     (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation: scene/gaussian_model.py:45-60) directly; same
     result dict, gradients land on the raw parameters.  Falls back to render() for the Python-side alternates."""
     if override_color is not None or pipe.convert_SHs_python or pipe.compute_cov3D_python:
-        return render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+        return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
     screenspace_points = _screenspace_points(pc)
     rs = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False)
     rendered_image, radii = rasterize_gaussians_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,

@@ -38,7 +38,8 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # process-wide knobs that are not part of the reference API
-_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False}
+_OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
+            "fuse_getters": True}
 
 
 def set_option(name, value):
@@ -46,6 +47,8 @@ def set_option(name, value):
     fast_exp (default True): hardware exp/rcp in render() -- training renders; set False for the canonical,
               bit-pinned arithmetic.  count renders (f_count=True) ALWAYS use the canonical arithmetic;
     profile: record per-kernel hipEvent timings (read with _lib.profile_read());
+    fuse_getters (default True): gaussian_renderer.render() evaluates the getters of a reference GaussianModel inside the
+              kernels (LG_FLAG_RAW_PARAMS) instead of in torch; False = the reference's literal getter pattern;
     skip_color_in_count: count renders do not evaluate colours (image = background-free zeros); for passes that only
               consume gaussians_count / important_score, e.g. prune_list_sharded."""
     if name not in _OPTIONS:

@@ -123,6 +123,11 @@ class SyntheticGaussians:
     active_sh_degree: int
     max_sh_degree: int
 
+    # scene/gaussian_model.py:36-47 setup_functions(): the activations are attributes of the model
+    scaling_activation = staticmethod(torch.exp)
+    opacity_activation = staticmethod(torch.sigmoid)
+    rotation_activation = staticmethod(torch.nn.functional.normalize)
+
     # scene/gaussian_model.py:98-118
     @property
     def get_xyz(self):
@@ -130,15 +135,15 @@ class SyntheticGaussians:
 
     @property
     def get_scaling(self):
-        return torch.exp(self._scaling)
+        return self.scaling_activation(self._scaling)
 
     @property
     def get_rotation(self):
-        return torch.nn.functional.normalize(self._rotation)
+        return self.rotation_activation(self._rotation)
 
     @property
     def get_opacity(self):
-        return torch.sigmoid(self._opacity)
+        return self.opacity_activation(self._opacity)
 
     @property
     def get_features(self):

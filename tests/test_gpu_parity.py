@@ -245,7 +245,9 @@ def test_fused_getters_match_unfused_render(deg):
     """render_fused (activations + cat inside the kernels) vs render() on the same raw parameters:
     image within 1e-5, gradients w.r.t. the RAW parameters within 1e-4 (different exp/sigmoid implementations only)."""
     import gpu_common
-    from lightgaussian_amd.gaussian_renderer import render, render_fused
+    from lightgaussian_amd import rasterizer
+    from lightgaussian_amd.gaussian_renderer import render as render_auto, render_fused, _render_unfused as render
+    assert rasterizer._OPTIONS["fuse_getters"] is True
     dev = torch.device("cuda:0")
     W, H, N = 200, 120, 5000
     cam = syn.orbit_camera(1, 5, W, H, radius=5.0).to(dev)
@@ -253,7 +255,7 @@ def test_fused_getters_match_unfused_render(deg):
     pipe = syn.PipelineParams()
     gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
     outs = []
-    for fn in (render, render_fused):
+    for fn in (render, render_fused, render_auto):
         g = syn.make_gaussians(N, sh_degree=deg, seed=4, log_scale_mean=math.log(0.04), opacity_mean=0.5, extent=(2, 1.2, 2)).to(dev)
         g.requires_grad_(True)
         pkg = fn(cam, g, pipe, bg)
@@ -261,7 +263,11 @@ def test_fused_getters_match_unfused_render(deg):
         outs.append((pkg["render"].detach().cpu().numpy(), pkg["radii"].cpu().numpy(), pkg["viewspace_points"].grad.cpu().numpy(),
                      [t.grad.cpu().numpy() if t.grad is not None else None
                       for t in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)]))
-    (ia, ra, va, ga), (ib, rb, vb, gb) = outs
+    (ia, ra, va, ga), (ib, rb, vb, gb), (ic, rc, vc, gc) = outs
+    # render() itself takes the fused path for a model with the reference's activations (option fuse_getters):
+    # bit-identical to the explicit render_fused call
+    assert np.array_equal(ic, ib) and np.array_equal(vc, vb) and all(
+        (x is None and y is None) or np.array_equal(x, y) for x, y in zip(gb, gc))
     assert np.array_equal(ra, rb)
     assert gpu_common.rel_err(ib, ia) <= 1e-5
     assert gpu_common.rel_err(vb, va) <= TOL
@@ -270,6 +276,28 @@ def test_fused_getters_match_unfused_render(deg):
             continue
         assert y is not None, name
         assert gpu_common.rel_err(y, x) <= TOL, f"{name}: {gpu_common.rel_err(y, x):.3e}"
+
+
+def test_fuse_getters_option_and_foreign_models_keep_the_literal_pattern():
+    """set_option('fuse_getters', False) and models without the reference's activation attributes go through the
+    reference's literal getter pattern (bit-identical to _render_unfused)."""
+    from lightgaussian_amd import rasterizer
+    from lightgaussian_amd.gaussian_renderer import render, _render_unfused, _has_reference_getters
+    from lightgaussian_amd.prune import _FrozenGetters
+    dev = torch.device("cuda:0")
+    cam = syn.orbit_camera(0, 5, 160, 96, radius=5.0).to(dev)
+    bg = torch.zeros(3, device=dev); pipe = syn.PipelineParams()
+    g = syn.make_gaussians(3000, sh_degree=3, seed=9, log_scale_mean=math.log(0.04)).to(dev)
+    ref = _render_unfused(cam, g, pipe, bg)["render"]
+    assert _has_reference_getters(g) and not _has_reference_getters(_FrozenGetters(g))
+    assert torch.equal(render(cam, _FrozenGetters(g), pipe, bg)["render"], ref)
+    rasterizer.set_option("fuse_getters", False)
+    try:
+        assert torch.equal(render(cam, g, pipe, bg)["render"], ref)
+    finally:
+        rasterizer.set_option("fuse_getters", True)
+    fused = render(cam, g, pipe, bg)["render"]
+    assert float((fused - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 def test_weight_policies_alpha_and_alpha_t():

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -30 > gpurun_out/pytest_gpu.log; tail -8 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
 for mode in "$@"; do
-  EXTRA=""; if [ "$mode" = "fused" ]; then mode=fwdbwd; EXTRA="--fused"; fi
+  EXTRA=""; if [ "$mode" = "nofuse" ]; then mode=fwdbwd; EXTRA="--no-fuse"; fi
   timeout 300 python bench.py --steps 50 --warmup 10 --mode $mode $EXTRA --no-cpu-baseline > gpurun_out/bench_$mode$EXTRA.log 2>&1; tail -1 gpurun_out/bench_$mode$EXTRA.log | python -c "
 import sys, json
 l=sys.stdin.read().strip()
@@ -14,3 +14,4 @@ try:
 except Exception as e: print('RAW', l[-2000:])
 "
 done
+echo "PYTEST: $(tail -1 gpurun_out/pytest_gpu.log)"; echo "SMOKE: $(tail -1 gpurun_out/smoke.log)"
