@@ -92,10 +92,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
-            // rows that are whole float4s and 16-byte aligned are read directly (no LDS); anything else is staged through LDS
-            const bool direct = g->shs && !g->shs_rest && (g->M % 4 == 0) && ((reinterpret_cast<uintptr_t>(g->shs) & 15u) == 0) &&
-                                getenv("LG_K1_LDS") == nullptr;
-            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PP(true, false);
+            // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
+            const bool direct = getenv("LG_K1_LDS") == nullptr;
+            const bool raw = v->flags & LG_FLAG_RAW_PARAMS;
+            if (raw && direct) LAUNCH_PP(true, true);
+            else if (raw) LAUNCH_PP(true, false);
             else if (direct) LAUNCH_PP(false, true);
             else LAUNCH_PP(false, false);
 #undef LAUNCH_PP

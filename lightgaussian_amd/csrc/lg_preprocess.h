@@ -37,6 +37,29 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
 // RAW (section 8f row 1, "fused getters"): the inputs are GaussianModel's raw parameters -- log-scales, unnormalised
 // quaternions, opacity logits, and the SH coefficients as the two tensors _features_dc [N,1,3] / _features_rest
 // [N,M-1,3] -- and the activations (scene/gaussian_model.py:98-118) are evaluated here instead of by torch.
+// SH rows are 3M (or 3(M-1)) floats, i.e. in general only 4-byte aligned (180 B for _features_rest at M = 16).  gfx950
+// global loads of 16 bytes need dword alignment only, so a lane reads its row with dwordx4 loads through a packed,
+// 4-byte-aligned float4 plus at most three trailing dwords -- no LDS staging, no alignment precondition.
+struct __attribute__((packed, aligned(4))) lg_f4u { float x, y, z, w; };
+template <int K0>
+__device__ __forceinline__ void read_row_direct(const float* __restrict__ row, int nfl, float* sh /*[LG_SH_MAXF]*/)
+{
+#pragma unroll
+    for (int q = 0; q < (LG_SH_MAXF - K0 + 3) / 4; q++) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (4 * q + 4 <= nfl) {
+            const lg_f4u t = reinterpret_cast<const lg_f4u*>(row)[q];
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (4 * q + c < nfl) v[c] = row[4 * q + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (K0 + 4 * q + c < LG_SH_MAXF) sh[K0 + 4 * q + c] = v[c];
+    }
+}
 __device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // 92 VGPRs -> 5 waves/SIMD.  Forcing 6 or 8 (amdgpu_waves_per_eu) spills 43 / 71 registers: measured 0.22 -> 0.28 / 0.45 ms.
@@ -49,8 +72,9 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
 {
-    // DIRECT: every visible lane reads its own 16-byte-aligned SH row with float4 loads and no LDS is allocated
-    // (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3); otherwise rows go through LDS.
+    // DIRECT (default): every visible lane reads its own SH row with dwordx4 loads (read_row_direct) and no LDS is
+    // allocated for SH (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3).  The LDS-staged
+    // variant is kept behind the LG_K1_LDS environment switch as the cross-check of the direct reads.
     __shared__ __attribute__((aligned(16))) float sh_rows[DIRECT ? 4 : LG_PP * LG_SH_MAXF];
     __shared__ float4 st_rec[LG_PP * 3], st_aux[LG_PP * 2]; // records leave through LDS as coalesced 16-byte stores
     static_assert(LG_REC_F4 == 3, "coalesced record store assumes packed 48-byte records");
@@ -116,7 +140,12 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 float sh[LG_SH_MAXF];
                 const float* row = DIRECT ? shs + (size_t)i * rowf : sh_rows + lane * rowf;
                 const int nact = (D + 1) * (D + 1) * 3;
-                if (split) {
+                if (split && DIRECT) {
+                    sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+                    read_row_direct<3>(shs_rest + (size_t)i * rowf, nact - 3, sh);
+                } else if (DIRECT) {
+                    read_row_direct<0>(row, nact, sh);
+                } else if (split) {
                     sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
 #pragma unroll
                     for (int k = 3; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k - 3] : 0.0f;

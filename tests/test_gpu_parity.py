@@ -300,6 +300,26 @@ def test_fuse_getters_option_and_foreign_models_keep_the_literal_pattern():
     assert float((fused - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("deg", [3, 2, 1, 0])
+def test_direct_and_lds_staged_sh_reads_agree(deg, monkeypatch):
+    """K1 reads SH rows with dword-aligned dwordx4 loads (rows of 3M / 3(M-1) floats are not 16-byte aligned in
+    general); the LDS-staged reader (LG_K1_LDS=1) must give bit-identical images, for activated tensors and for the raw
+    dc/rest pair, including the last rows of the tensors (N not a multiple of 64)."""
+    from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused
+    dev = torch.device("cuda:0")
+    cam = syn.orbit_camera(2, 7, 176, 112, radius=5.0).to(dev)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=dev); pipe = syn.PipelineParams()
+    g = syn.make_gaussians(4099, sh_degree=deg, seed=11, log_scale_mean=math.log(0.04), rest_std=0.3).to(dev)
+    for fn in (_render_unfused, render_fused):
+        monkeypatch.delenv("LG_K1_LDS", raising=False)
+        a = fn(cam, g, pipe, bg)["render"].clone()
+        monkeypatch.setenv("LG_K1_LDS", "1")
+        b = fn(cam, g, pipe, bg)["render"].clone()
+        monkeypatch.delenv("LG_K1_LDS", raising=False)
+        assert torch.equal(a, b), fn.__name__
+        assert float(a.abs().max()) > 0
+
+
 def test_weight_policies_alpha_and_alpha_t():
     """The float per-hit weights (ALPHA, ALPHA_T) are order-dependent sums even in the reference; tolerance 1e-4.
     ONE gives score == count exactly."""
