@@ -59,6 +59,7 @@ def parse():
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
     ap.add_argument("--cpu-baseline-n", type=int, default=0, help="Gaussians in the CPU sample (0 = same as workload)")
     return ap.parse_args()
 
@@ -283,13 +284,13 @@ def main():
         # calibration on lg_preprocess_bwd confirms: WRITE_SIZE matches the known 744 MB of stores exactly, raw
         # FETCH_SIZE is 0.57x the known reads).  null when no PMC file for this workload is present.
         try:
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic_fwdbwd.json")
+            tpath = os.path.join(ROOT, "profiles", "r01_final_traffic_fwdbwd.json")
             tj = json.load(open(tpath))
             key = {"blend_bwd": "lg_blend_bwd", "blend_fwd": "lg_blend_fwd", "blend_fwd_count": "lg_blend_fwd", "preprocess": "lg_preprocess",
                    "preprocess_bwd": "lg_preprocess_bwd"}.get(dom)
             if key in tj and args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080):
                 result["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch_high"]
-                result["roofline"]["traffic_source"] = "profiles/r01_traffic_fwdbwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+                result["roofline"]["traffic_source"] = "profiles/r01_final_traffic_fwdbwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; 2*FETCH+WRITE = upper estimate, FETCH+WRITE = %d)" % tj[key]["hbm_bytes_per_launch_low"]
         except Exception:
             pass
         result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
@@ -297,7 +298,7 @@ def main():
         result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
 
     # ---- the same step with the reference's literal getter pattern (torch exp/sigmoid/normalize/cat per call), untimed leg ----
-    if rank == 0 and not args.no_fuse and args.mode in ("fwdbwd", "fwd", "distill"):
+    if rank == 0 and not args.no_fuse and not args.no_literal and args.mode in ("fwdbwd", "fwd", "distill"):
         rasterizer.set_option("fuse_getters", False)
         nlit = max(5, min(30, args.steps))
         for i in range(3):

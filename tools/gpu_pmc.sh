@@ -6,7 +6,7 @@ cd /tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc$i -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc$i -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-literal > $R/gpurun_out/pmc$i.log 2>&1
   echo "set $i rc=$?"
   find $R/gpurun_out/pmc$i -name '*.csv' | head
 done

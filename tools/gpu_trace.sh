@@ -4,7 +4,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 MODE=${1:-fwdbwd}
 cd /tmp
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$MODE -o t -- python $R/bench.py --steps 20 --warmup 5 --mode $MODE --no-cpu-baseline --no-roofline > $R/gpurun_out/trace_$MODE.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$MODE -o t -- python $R/bench.py --steps 20 --warmup 5 --mode $MODE --no-cpu-baseline --no-roofline --no-literal > $R/gpurun_out/trace_$MODE.log 2>&1
 echo "rc=$?"
 cd $R
 ls -la gpurun_out/trace_$MODE | head

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 MODE=${1:-fwdbwd}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$C -o p -- python $R/bench.py --steps 3 --warmup 1 --mode $MODE --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_$C.log 2>&1
+  timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$C -o p -- python $R/bench.py --steps 3 --warmup 1 --mode $MODE --no-cpu-baseline --no-roofline --no-literal > $R/gpurun_out/pmc_$C.log 2>&1
   echo "$C rc=$?"
 done
 cd $R
