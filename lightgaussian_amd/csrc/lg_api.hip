@@ -147,8 +147,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
             if (packed)
-                HIP_TRY(hipcub::DeviceRadixSort::SortKeys(bin.sort_temp, tb, bin.keys_in, bin.keys_out, (int)R, gid_bits,
-                                                          gid_bits + depth_bits + tile_bits, stream));
+                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.keys_out, (unsigned)R, (unsigned)gid_bits,
+                                     (unsigned)(gid_bits + depth_bits + tile_bits), stream));
             else
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
                                                            32 + tile_bits, stream));

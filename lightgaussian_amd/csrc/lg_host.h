@@ -114,6 +114,32 @@ static GeomView carve_geom(void* base, int N)
     return g;
 }
 
+// K4: keys-only radix sort of the packed 64-bit keys (rocPRIM onesweep).  rocPRIM's tuned gfx950 configuration for
+// 8-byte keys is 512 threads x 12 keys per block; for the ~4 M instances of a view a sweep on MI355X measured
+// (sort ms at C3): 256x8 0.379, 256x12 0.310, 256x16 0.284, 512x6 0.290, 512x12 (rocPRIM default) 0.237, 512x16 0.238,
+// 1024x4 0.255, 1024x6 0.229, **1024x8 0.209**, 1024x10 0.241, 1024x12 0.256, 1024x16 0.218; 10 radix bits: 0.273.
+// -DLG_SORT_ROCPRIM_DEFAULT restores rocPRIM's own choice.
+#ifndef LG_SORT_BLOCK
+#define LG_SORT_BLOCK 1024
+#define LG_SORT_ITEMS 8
+#endif
+#ifndef LG_SORT_BITS
+#define LG_SORT_BITS 8
+#endif
+#ifdef LG_SORT_ROCPRIM_DEFAULT
+using lg_sort_config = rocprim::default_config;
+#else
+using lg_sort_config = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>, rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>,
+                                        LG_SORT_BITS, rocprim::block_radix_rank_algorithm::match>>;
+#endif
+static inline hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, uint64_t* keys_in, uint64_t* keys_out, unsigned n, unsigned begin_bit,
+                                      unsigned end_bit, hipStream_t stream)
+{
+    return rocprim::radix_sort_keys<lg_sort_config>(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, stream);
+}
+
 struct ImgView { float* final_T; uint32_t* n_contrib; size_t total; };
 static ImgView carve_img(void* base, int W, int H)
 {
@@ -157,7 +183,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     v.keys_out = (uint64_t*)take(n * 8);
     size_t tb = 0;
     if (packed) {
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, 0, 64);
+        (void)lg_sort_keys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)n, 0, 64, nullptr);
     } else {
         v.slot_in = (uint32_t*)take(n * 4);
         v.gid_slot = (uint32_t*)take(n * 4);
