@@ -156,7 +156,7 @@ def main():
             return loss_utils.l1_dssim_loss(image, gt, 0.2)[0]
         return 0.8 * (image - gt).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt))
 
-    def step(i):
+    def step(i, collectives=True):
         k = my_views[i % len(my_views)]
         if args.mode == "fwdbwd":
             if k not in gts:
@@ -176,7 +176,8 @@ def main():
                 target = render(cams[k], pc, pipe, bg)["render"]
             loss = (render(cams[k], student, pipe, bg)["render"] - target).abs().mean()
             loss.backward()
-            parallel.allreduce_gradients(sparams)
+            if collectives:   # the rank-0-only measurement legs below must not enter a collective
+                parallel.allreduce_gradients(sparams)
         else:
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
@@ -266,7 +267,7 @@ def main():
         _lib.profile_reset()
         nprof = max(3, min(10, args.steps))
         for i in range(nprof):
-            step(i)
+            step(i, collectives=False)
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         rasterizer.set_option("profile", False)
@@ -302,11 +303,11 @@ def main():
         rasterizer.set_option("fuse_getters", False)
         nlit = max(5, min(30, args.steps))
         for i in range(3):
-            step(i)
+            step(i, collectives=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(nlit):
-            step(i)
+            step(i, collectives=False)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / nlit
         rasterizer.set_option("fuse_getters", True)
