@@ -314,6 +314,28 @@ def main():
         result["literal_getter_pattern"] = {"views_per_s_per_gpu": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 4), "steps": nlit,
                                             "note": "set_option('fuse_getters', False): getters evaluated by torch on every render call, as the reference does"}
 
+    # ---- the other two rates north_star asks for, on the same scene (rank 0, untimed w.r.t. `value`, no collectives) ----
+    if rank == 0 and args.mode == "fwdbwd" and not args.no_literal:
+        from lightgaussian_amd.prune import _FrozenGetters
+        def rate(fn, n=30):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return n / (time.perf_counter() - t0)
+        with torch.no_grad():
+            fwd_rate = rate(lambda i: render(cams[my_views[i % len(my_views)]], pc, pipe, bg))
+            frozen = _FrozenGetters(pc)
+            rasterizer.set_option("skip_color_in_count", True)
+            cnt_rate = rate(lambda i: count_render(cams[my_views[i % len(my_views)]], frozen, pipe, bg))
+            rasterizer.set_option("skip_color_in_count", False)
+        result["same_scene_rates_per_gpu"] = {"fwd_views_per_s": round(fwd_rate, 2), "significance_count_views_per_s": round(cnt_rate, 2),
+                                              "note": "render() under no_grad; count_render per view as in prune_list_sharded (getters hoisted, "
+                                                      "colours skipped); see --mode fwd / --mode count for the full runs"}
+
     # ---- cpu_baseline leg: the oracle on the host cores, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, g_cpu, W, H)
@@ -347,7 +369,7 @@ def cpu_baseline(args, g_cpu, W, H):
                   campos=cam.camera_center.numpy(), sh_degree=args.sh_degree)
     count = args.mode == "count"
     t0 = time.perf_counter()
-    f = oracle.forward(count=count, **kw)
+    f = oracle.forward(count=True, **kw)   # the count accumulation rides along (a few adds per hit): one oracle pass serves both parities
     t_f = time.perf_counter() - t0
     t_b = 0.0
     gimg = np.random.RandomState(0).randn(3, H, W).astype(np.float32) / (3 * H * W)
@@ -372,9 +394,20 @@ def cpu_baseline(args, g_cpu, W, H):
     mse = float((err ** 2).mean())
     par = {"image_psnr_db": (round(10 * math.log10(1.0 / mse), 2) if mse > 0 else "inf (bit-identical)"),
            "image_max_abs_err": float(np.abs(err).max()), "radii_equal": bool(np.array_equal(res[-1].cpu().numpy(), f.radii))}
-    if count:
-        par["hit_counts_equal"] = bool(np.array_equal(res[0].cpu().numpy(), f.count))
-        par["scores_bit_identical"] = bool(np.array_equal(res[1].cpu().numpy().view(np.uint32), f.score.view(np.uint32)))
+    if not count:   # significance outputs of the same view through the count variant (canonical arithmetic)
+        rs_c = rs._replace(f_count=True)
+        with torch.no_grad():
+            res_c = GaussianRasterizer(rs_c)(means3D=d["means3D"].detach(), means2D=means2D.detach(), opacities=d["opacities"].detach(),
+                                             shs=d["shs"].detach(), scales=d["scales"].detach(), rotations=d["rotations"].detach())
+    else:
+        res_c = res
+    h_cnt, h_score = res_c[0].cpu().numpy(), res_c[1].cpu().numpy()
+    par["hit_counts_equal"] = bool(np.array_equal(h_cnt, f.count))
+    par["scores_bit_identical"] = bool(np.array_equal(h_score.view(np.uint32), f.score.view(np.uint32)))
+    sc = g_cpu.get_scaling[:n].detach().numpy()
+    m_hip = oracle.prune_mask(0.66, oracle.calculate_v_imp_score(sc, h_score, 0.1))
+    m_ref = oracle.prune_mask(0.66, oracle.calculate_v_imp_score(sc, f.score, 0.1))
+    par["prune_mask_hamming_distance"] = int((m_hip != m_ref).sum())
     if args.mode == "fwdbwd":
         (img * torch.from_numpy(gimg).to(dev)).sum().backward()
         rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
