@@ -294,6 +294,24 @@ def main():
                 result["roofline"]["traffic_source"] = "profiles/r01_final_traffic_fwdbwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; 2*FETCH+WRITE = upper estimate, FETCH+WRITE = %d)" % tj[key]["hbm_bytes_per_launch_low"]
         except Exception:
             pass
+        # the blend kernels are VALU-issue-bound, not HBM-bound (SURVEY 8d caveat): say so with numbers.  VALU wave64
+        # instructions per launch from the committed PMC pass (profiles/r01_final_pmc_valu.json, SQ_INSTS_VALU), the
+        # launch duration measured live above, instruction costs from tools/ubench/valu_rate*.hip on MI355X.
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_valu.json")))
+            pk = {"blend_bwd": "lg_blend_bwd<false>", "blend_fwd": "lg_blend_fwd<false, false, false>"}.get(dom)
+            if pk in pj and args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080) and not args.exact_exp:
+                ninst = pj[pk]["SQ_INSTS_VALU"]
+                clk_ghz, simds = 2.4, 1024
+                result["roofline"]["valu_issue"] = {
+                    "wave64_valu_instr_per_launch": ninst, "G_instr_per_s": round(ninst / avg_s / 1e9, 1),
+                    "cycles_per_instr_per_simd": round(avg_s * clk_ghz * 1e9 * simds / ninst, 2),
+                    "measured_instr_cost_cycles": {"fma/mul/add/mov": 2.7, "cmp/cndmask/min/max": 4.5, "dpp_add": 4.4, "exp": 8.4, "rcp": 9.4},
+                    "note": "VALU-issue-bound kernel: cycles per instruction per SIMD is at the cost of its instruction mix; "
+                            "the HBM fraction above is reported because the contract asks for it, it is not this kernel's limiter",
+                    "source": "profiles/r01_final_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) + tools/ubench"}
+        except Exception:
+            pass
         result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
         tot_bytes = sum(ab[k] * per_kernel[k]["launches_per_step"] for k in per_kernel if k in ab)
         result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
