@@ -154,6 +154,15 @@ size_t lg_prune_scratch_bytes(int32_t N);
 int lg_prune_epilogue(int32_t N, const float* scaling, const float* imp_list, float v_pow, double prune_percent,
                       float* v_list, uint8_t* mask, float* thresholds, void* scratch, uint32_t flags, void* stream);
 
+/* --- distCUDA2 (first half) -------------------------------------------------------
+ * Replaces the reference's simple-knn extension: submodules/simple-knn/spatial.cu:15-27 distCUDA2() ->
+ * simple_knn.cu:185-221 SimpleKNN::knn(): mean_dist2[i] = (d0 + d1 + d2) / 3 with d0 <= d1 <= d2 the three smallest
+ * squared Euclidean distances from points[i] to the OTHER points (by index: coincident points count with distance 0;
+ * fewer than 4 points leave FLT_MAX placeholders in the sum, as in simple_knn.cu:150,182).  Exact.
+ * points [P,3] fp32 device, mean_dist2 [P] fp32 device, scratch: lg_knn_scratch_bytes(P) device bytes.  No host sync. */
+size_t lg_knn_scratch_bytes(int32_t P);
+int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* scratch, uint32_t flags, void* stream);
+
 /* --- photometric loss of the training step -------------------------------------
  * Replaces utils/loss_utils.py:18-19 l1_loss() and :46-85 ssim() (11x11 Gaussian window sigma 1.5 of :26-43,
  * conv2d zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over all C*H*W), as combined at prune_finetune.py:161-164:

@@ -7,6 +7,7 @@
 //   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_finalize_bins   (per instance; K2/K4 = rocPRIM scan / radix sort)
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
+//   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
 //   lg_blend.h       K6 lg_blend_fwd<COUNT,FSCORE,EXACT>, lg_score_kernel, K7 lg_blend_bwd<EXACT>   (per tile, VALU-bound)
 //
 // Pipeline of one view:
@@ -23,6 +24,7 @@
 #include "lg_blend.h"
 #include "lg_loss.h"
 #include "lg_prune.h"
+#include "lg_knn.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -309,6 +311,43 @@ extern "C" int lg_prune_epilogue(int32_t N, const float* scaling, const float* i
     }
     lg_prune_mask_kernel<<<blocks, 256, 0, stream>>>(N, rank_score, v_list, &st[1], mask, thresholds);
     KCHECK("lg_prune_mask_kernel");
+    return LG_OK;
+}
+
+extern "C" size_t lg_knn_scratch_bytes(int32_t P) { return P < 0 ? 0 : carve_knn(nullptr, P).total; }
+
+extern "C" int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* scratch, uint32_t flags, void* stream_p)
+{
+    if (P < 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad point count");
+    if (P == 0) return LG_OK;
+    if (!points || !mean_dist2 || !scratch) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
+    KnnView kv = carve_knn(scratch, P);
+    ProfScope ps(prof, "knn3", stream);
+    HIP_TRY(hipMemsetAsync(kv.box, 0xFF, 12, stream));                 // min keys
+    HIP_TRY(hipMemsetAsync(kv.box + 3, 0, 64 - 12, stream));           // max keys, open-point counters
+    const int nb = (P + 255) / 256;
+    lg_knn_bbox<<<std::min(nb, 1024), 256, 0, stream>>>(P, points, kv.box);
+    KCHECK("lg_knn_bbox");
+    int key_bits = 1;
+    while ((1u << key_bits) < kv.cap) key_bits++;
+    for (int level = 0; level < LG_KNN_LEVELS; level++) {
+        lg_knn_cells<<<nb, 256, 0, stream>>>(P, kv.cap, level, points, kv.box, kv.keys_in, kv.vals_in);
+        KCHECK("lg_knn_cells");
+        size_t tb = kv.sort_temp_bytes;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(kv.sort_temp, tb, kv.keys_in, kv.keys_out, kv.vals_in, kv.vals_out, P, 0, key_bits, stream));
+        HIP_TRY(hipMemsetAsync(kv.cell_start, 0, (size_t)kv.cap * 4, stream));
+        HIP_TRY(hipMemsetAsync(kv.cell_end, 0, (size_t)kv.cap * 4, stream));
+        lg_knn_ranges<<<nb, 256, 0, stream>>>(P, points, kv.keys_out, kv.vals_out, kv.cell_start, kv.cell_end, kv.sorted);
+        KCHECK("lg_knn_ranges");
+        uint32_t* open_in = (level & 1) ? kv.open_a : kv.open_b;
+        uint32_t* open_out = (level & 1) ? kv.open_b : kv.open_a;
+        const int max_rings = level == LG_KNN_LEVELS - 1 ? (1 << 30) : LG_KNN_RINGS;
+        lg_knn_query<<<nb, 256, 0, stream>>>(P, kv.cap, level, max_rings, points, kv.box, kv.sorted, kv.cell_start, kv.cell_end, open_in,
+                                             kv.box + 8 + (level > 0 ? level - 1 : 0), open_out, kv.box + 8 + level, mean_dist2);
+        KCHECK("lg_knn_query");
+    }
     return LG_OK;
 }
 

@@ -1,0 +1,217 @@
+// lg_knn.h -- distCUDA2: mean squared distance of every point to its 3 nearest OTHER points (exact).
+// Replaces submodules/simple-knn (simple_knn.cu:185-221 SimpleKNN::knn, spatial.cu:15-27 distCUDA2), the initialiser of
+// the Gaussians' scales (scene/gaussian_model.py:152-156).  The reference sorts points along a Morton curve, boxes them
+// 1024 at a time and lets every point test EVERY box (O(P^2/1024)).  Here: a uniform grid with ~2 points per cubic cell
+// built by one radix sort of cell ids, and a ring search around the query's cell that stops as soon as the third-best
+// distance is provably final (everything unseen after ring r is at least r cell sizes away).  Points still open after
+// LG_KNN_RINGS rings (sparse regions, outliers) are retried on grids with 4x, 16x, 64x, 256x larger cells; the last
+// level searches until its rings cover the whole grid, so every point terminates with the exact answer.  No host round
+// trip: the bounding box, the grid shape and the open-point lists live in device memory.
+// Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
+#pragma once
+
+#include "lg_host.h"
+#include "lg_wave.h"
+#include "lg_prune.h" // lg_order_key
+#include <float.h>
+
+#define LG_KNN_RINGS 3      // rings searched per level before a point moves on to the next coarser grid
+#define LG_KNN_LEVELS 5     // cell size x1, x4, x16, x64, x256 (the last level has no ring limit)
+#define LG_KNN_MAX_AXIS 1024
+
+struct LgKnnGrid {
+    float min[3];
+    float inv_cell;   // 1 / cell size
+    float cell;       // cell size (cubic cells)
+    int g[3];         // cells per axis
+};
+
+// bounding box as order-preserving uint keys: box[0..2] = min, box[3..5] = max
+__global__ void __launch_bounds__(256)
+lg_knn_bbox(int P, const float* __restrict__ pts, uint32_t* __restrict__ box)
+{
+    __shared__ uint32_t smin[3][4], smax[3][4];
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const uint32_t k = lg_order_key(pts[3 * (size_t)i + a]);
+            mn[a] = min(mn[a], k); mx[a] = max(mx[a], k);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], sh));
+            mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], sh));
+        }
+        if ((threadIdx.x & 63) == 0) { smin[a][threadIdx.x >> 6] = mn[a]; smax[a][threadIdx.x >> 6] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        atomicMin(&box[a], min(min(smin[a][0], smin[a][1]), min(smin[a][2], smin[a][3])));
+        atomicMax(&box[3 + a], max(max(smax[a][0], smax[a][1]), max(smax[a][2], smax[a][3])));
+    }
+}
+
+// grid shape from the bounding box: cubic cells sized for ~2 points per cell, at most cap cells in total
+__device__ __forceinline__ LgKnnGrid lg_knn_grid(const uint32_t* __restrict__ box, int P, uint32_t cap, int level)
+{
+    LgKnnGrid G;
+    float ext[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        G.min[a] = lg_order_key_inv(box[a]);
+        ext[a] = fmaxf(lg_order_key_inv(box[3 + a]) - G.min[a], 0.0f);
+    }
+    const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+    // degenerate axes (flat or collinear clouds) get one cell; volume over the non-degenerate axes only
+    const float tiny = emax * 1e-6f;
+    float vol = 1.0f; int dims = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        if (ext[a] > tiny) { vol *= ext[a]; dims++; }
+    float cell = emax > 0.0f ? emax : 1.0f;
+    if (dims > 0) cell = powf(vol / fmaxf(0.5f * (float)P, 1.0f), 1.0f / (float)dims);
+    cell = fmaxf(cell, emax / (float)LG_KNN_MAX_AXIS);
+    if (!(cell > 0.0f)) cell = 1.0f;
+    for (int it = 0; it < 32; it++) {                 // grow the cells until the grid fits the budget
+#pragma unroll
+        for (int a = 0; a < 3; a++) G.g[a] = min(LG_KNN_MAX_AXIS, (int)(ext[a] / cell) + 1);
+        if ((uint64_t)G.g[0] * G.g[1] * G.g[2] <= cap) break;
+        cell *= 1.26f;
+    }
+    if (level > 0) {
+        cell *= (float)(1 << (2 * level));
+#pragma unroll
+        for (int a = 0; a < 3; a++) G.g[a] = min(LG_KNN_MAX_AXIS, (int)(ext[a] / cell) + 1);
+    }
+    G.cell = cell; G.inv_cell = 1.0f / cell;
+    return G;
+}
+__device__ __forceinline__ int lg_knn_coord(const LgKnnGrid& G, float v, int a)
+{
+    return min(G.g[a] - 1, max(0, (int)((v - G.min[a]) * G.inv_cell)));
+}
+
+__global__ void __launch_bounds__(256)
+lg_knn_cells(int P, uint32_t cap, int level, const float* __restrict__ pts, const uint32_t* __restrict__ box, uint32_t* __restrict__ keys,
+             uint32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const LgKnnGrid G = lg_knn_grid(box, P, cap, level);
+    const int cx = lg_knn_coord(G, pts[3 * (size_t)i], 0), cy = lg_knn_coord(G, pts[3 * (size_t)i + 1], 1),
+              cz = lg_knn_coord(G, pts[3 * (size_t)i + 2], 2);
+    keys[i] = (uint32_t)((cz * G.g[1] + cy) * G.g[0] + cx);
+    vals[i] = (uint32_t)i;
+}
+
+// after the sort: cell ranges and a cell-ordered copy of the points {x, y, z, original index}
+__global__ void __launch_bounds__(256)
+lg_knn_ranges(int P, const float* __restrict__ pts, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+              uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_end, float4* __restrict__ sorted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t k = keys[i], id = vals[i];
+    sorted[i] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
+    if (i == 0 || keys[i - 1] != k) cell_start[k] = (uint32_t)i;
+    if (i == P - 1 || keys[i + 1] != k) cell_end[k] = (uint32_t)i + 1u;
+}
+
+// simple_knn.cu:129-145 updateKBest<3>: insertion into the ascending triple
+__device__ __forceinline__ void lg_knn_update(float d, float& b0, float& b1, float& b2)
+{
+    if (b0 > d) { const float t = b0; b0 = d; d = t; }
+    if (b1 > d) { const float t = b1; b1 = d; d = t; }
+    if (b2 > d) { b2 = d; }
+}
+__device__ __forceinline__ float lg_knn_dist2(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = bx - ax, dy = by - ay, dz = bz - az;   // simple_knn.cu:132-133
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// One level of the search.  Level 0: thread t handles the point at sorted position t (neighbouring threads share cells).
+// Levels > 0: thread t handles open point open_in[t] (original index).  Points that are still open go to open_out.
+__global__ void __launch_bounds__(256)
+lg_knn_query(int P, uint32_t cap, int level, int max_rings, const float* __restrict__ pts, const uint32_t* __restrict__ box,
+             const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_end,
+             const uint32_t* __restrict__ open_in, const uint32_t* __restrict__ n_open_in, uint32_t* __restrict__ open_out,
+             uint32_t* __restrict__ n_open_out, float* __restrict__ out)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    float qx, qy, qz; uint32_t id;
+    if (level == 0) {
+        if (t >= (uint32_t)P) return;
+        const float4 q = sorted[t];
+        qx = q.x; qy = q.y; qz = q.z; id = __float_as_uint(q.w);
+    } else {
+        if (t >= *n_open_in) return;
+        id = open_in[t];
+        qx = pts[3 * (size_t)id]; qy = pts[3 * (size_t)id + 1]; qz = pts[3 * (size_t)id + 2];
+    }
+    const LgKnnGrid G = lg_knn_grid(box, P, cap, level);
+    const int cx = lg_knn_coord(G, qx, 0), cy = lg_knn_coord(G, qy, 1), cz = lg_knn_coord(G, qz, 2);
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    bool done = false;
+    const int rmax = max(G.g[0], max(G.g[1], G.g[2]));
+    for (int r = 0; r <= max_rings && !done; r++) {
+        for (int z = max(cz - r, 0); z <= min(cz + r, G.g[2] - 1); z++)
+            for (int y = max(cy - r, 0); y <= min(cy + r, G.g[1] - 1); y++) {
+                const bool edge_zy = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+                // on the shell of ring r: the whole x row when z or y is on the shell, else only its two end cells
+                const int xs = edge_zy ? 1 : max(2 * r, 1);
+                for (int x = cx - r; x <= cx + r; x += xs) {
+                    if (x < 0 || x >= G.g[0]) continue;
+                    const uint32_t c = (uint32_t)((z * G.g[1] + y) * G.g[0] + x);
+                    const uint32_t e = cell_end[c];
+                    for (uint32_t j = cell_start[c]; j < e; j++) {
+                        const float4 p = sorted[j];
+                        if (__float_as_uint(p.w) == id) continue;          // self (by index: duplicates of the position count)
+                        lg_knn_update(lg_knn_dist2(qx, qy, qz, p.x, p.y, p.z), b0, b1, b2);
+                    }
+                }
+            }
+        // unseen points lie in cells at Chebyshev distance >= r + 1, i.e. at least r cell sizes away
+        // (0.9999: the cell index is computed in float, keep the bound on the safe side of its rounding)
+        const float bound = (float)r * G.cell * 0.9999f;
+        done = (b2 <= bound * bound) || (r >= rmax);
+    }
+    if (done) out[id] = (b0 + b1 + b2) / 3.0f;                              // simple_knn.cu:182
+    else open_out[atomicAdd(n_open_out, 1u)] = id;
+}
+
+struct KnnView {
+    uint32_t* box;        // [16]: 6 bbox keys, [8 + level] = number of points still open after that level
+    uint32_t *keys_in, *keys_out, *vals_in, *vals_out;
+    uint32_t *cell_start, *cell_end;
+    float4* sorted;
+    uint32_t *open_a, *open_b;
+    void* sort_temp; size_t sort_temp_bytes;
+    uint32_t cap;
+    size_t total;
+};
+static KnnView carve_knn(void* base, int P)
+{
+    KnnView v; size_t off = 0; char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    uint32_t cap = 1024;
+    while (cap < n && cap < (1u << 24)) cap <<= 1;      // cells <= next power of two of P (>= 1 point per 2 cells on average)
+    v.cap = cap;
+    v.box = (uint32_t*)take(64);
+    v.keys_in = (uint32_t*)take(n * 4); v.keys_out = (uint32_t*)take(n * 4);
+    v.vals_in = (uint32_t*)take(n * 4); v.vals_out = (uint32_t*)take(n * 4);
+    v.cell_start = (uint32_t*)take((size_t)cap * 4); v.cell_end = (uint32_t*)take((size_t)cap * 4);
+    v.sorted = (float4*)take(n * 16);
+    v.open_a = (uint32_t*)take(n * 4); v.open_b = (uint32_t*)take(n * 4);
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
+    v.sort_temp_bytes = tb; v.sort_temp = take(tb);
+    v.total = off;
+    return v;
+}

@@ -1,37 +1,31 @@
-"""distCUDA2 for ROCm, written against the reference's call site only
-(scene/gaussian_model.py:152-156:  dist2 = torch.clamp_min(distCUDA2(points.float().cuda()), 0.0000001)).
+"""distCUDA2 for ROCm: drop-in for the reference's simple-knn extension (submodules/simple-knn/spatial.cu:15-27 ->
+simple_knn.cu:185-221), consumed at scene/gaussian_model.py:152-156:
 
-Semantics of the reference extension (submodules/simple-knn/simple_knn.cu:147-183,185-221): for every point the
-MEAN of the squared Euclidean distances to its 3 nearest other points.  The CUDA original finds them with a
-Morton-order sweep; this is an exact, chunked brute force on the tensor's own device (torch ops, runs on HIP):
-O(N^2) distance evaluations in tiles of `chunk` x N, which for SfM-sized clouds (1e4..1e6 points, called once at
-start-up) is seconds at most on an MI355X.  Init-only plumbing -- deliberately not a hand-written kernel.
+    dist2 = torch.clamp_min(distCUDA2(torch.from_numpy(np.asarray(pcd.points)).float().cuda()), 0.0000001)
+
+mean of the squared distances to the 3 nearest other points, exact.  Runs on the HIP library
+(lg_knn3_mean_dist2: multi-level uniform grid, one radix sort per level, no host sync); there is no CPU / PyTorch
+fallback -- CPU tensors raise, like the CUDA extension does.
 """
+import ctypes as C
+
 import torch
 
 
-def distCUDA2(points: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """points [P,3] float -> [P] float: mean squared distance to the 3 nearest neighbours (self excluded)."""
+def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+    """points [P,3] float32 on the GPU -> [P] float32."""
+    from lightgaussian_amd import _lib
     if points.dim() != 2 or points.shape[1] != 3:
         raise ValueError("distCUDA2 expects a [P,3] tensor")
-    pts = points.float().contiguous()
+    if not points.is_cuda:
+        raise RuntimeError("distCUDA2 runs on the MI355X HIP library only (no CPU fallback); pass a .cuda() tensor")
+    pts = points.detach().float().contiguous()
     P = pts.shape[0]
-    out = torch.empty(P, dtype=torch.float32, device=pts.device)
+    means = torch.full((P,), 0.0, dtype=torch.float32, device=pts.device)    # spatial.cu:21
     if P == 0:
-        return out
-    k = min(4, P)  # self + 3 neighbours
-    sq = (pts * pts).sum(1)
-    for s in range(0, P, chunk):
-        q = pts[s:s + chunk]
-        d2 = (sq[s:s + chunk, None] + sq[None, :] - 2.0 * (q @ pts.t())).clamp_min_(0.0)
-        idx = torch.arange(s, min(s + chunk, P), device=pts.device)
-        d2[torch.arange(idx.numel(), device=pts.device), idx] = float("inf")  # exclude self exactly
-        nn = torch.topk(d2, k - 1, dim=1, largest=False).values if k > 1 else torch.zeros(idx.numel(), 1, device=pts.device)
-        # exact recomputation of the selected distances (the expanded form above loses precision for near-duplicates)
-        sel = torch.topk(d2, k - 1, dim=1, largest=False).indices if k > 1 else None
-        if sel is not None:
-            diff = q[:, None, :] - pts[sel]
-            nn = (diff * diff).sum(-1)
-        # the reference divides the sum of the 3 best by 3 (simple_knn.cu:182) even if fewer than 3 neighbours exist
-        out[s:s + chunk] = nn.sum(1) / 3.0
-    return out
+        return means
+    lib = _lib.load()
+    scratch = torch.empty(lib.lg_knn_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
+    _lib.check(lib.lg_knn3_mean_dist2(P, pts.data_ptr(), means.data_ptr(), scratch.data_ptr(), 0,
+                                      C.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream)))
+    return means

@@ -1,0 +1,97 @@
+"""distCUDA2 (simple-knn replacement): CPU tests of the oracle against hand-derived known answers and brute force,
+import shape of the drop-in module; GPU tests of lg_knn3_mean_dist2 against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_oracle as KO
+
+
+def _brute(p):
+    p = p.astype(np.float64)
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    return np.sort(d2, axis=1)[:, :3].mean(1)
+
+
+def test_oracle_known_answers():
+    # four corners of a unit square in the z = 0 plane: neighbours at 1, 1, sqrt(2) -> (1 + 1 + 2) / 3
+    sq = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    assert np.allclose(KO.dist_cuda2(sq), 4.0 / 3.0)
+    # coincident points are neighbours at distance 0 (self is excluded by index only, simple_knn.cu:159,173)
+    tw = np.array([[0, 0, 0], [0, 0, 0], [2, 0, 0], [0, 3, 0]], np.float32)
+    assert np.allclose(KO.dist_cuda2(tw), [(0 + 4 + 9) / 3, (0 + 4 + 9) / 3, (4 + 4 + 13) / 3, (9 + 9 + 13) / 3])
+    # fewer than 4 points: the FLT_MAX placeholders of simple_knn.cu:150 stay in the sum
+    assert np.isinf(KO.dist_cuda2(np.zeros((1, 3), np.float32))).all()
+    assert np.isinf(KO.dist_cuda2(np.array([[0, 0, 0], [1, 0, 0]], np.float32))).all()                 # d0 + FLT_MAX + FLT_MAX overflows
+    three = KO.dist_cuda2(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32))                     # d0 + d1 + FLT_MAX does not
+    assert np.isfinite(three).all() and (three > 1e38).all()
+    assert KO.dist_cuda2(np.zeros((0, 3), np.float32)).shape == (0,)
+
+
+def test_oracle_matches_brute_force():
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(600, 3)).astype(np.float32)
+    p[10] = p[11] + 1e-4
+    assert np.allclose(KO.dist_cuda2(p), _brute(p), rtol=1e-4, atol=1e-9)
+
+
+def test_drop_in_module_shape_and_no_cpu_fallback():
+    from simple_knn._C import distCUDA2           # scene/gaussian_model.py:20
+    with pytest.raises(RuntimeError):
+        distCUDA2(torch.rand(10, 3))
+    with pytest.raises(ValueError):
+        distCUDA2(torch.rand(10, 2))
+
+
+CLOUDS = {
+    "uniform": lambda rng, n: rng.random((n, 3)),
+    "gaussian_clusters": lambda rng, n: (rng.normal(size=(n, 3)) * 0.01 + rng.integers(0, 5, (n, 1)) * np.array([[1.0, 0.3, 2.0]])),
+    "flat": lambda rng, n: np.concatenate([rng.random((n, 2)), np.zeros((n, 1))], 1),
+    "line": lambda rng, n: np.concatenate([rng.random((n, 1)) * 10, np.full((n, 2), 0.5)], 1),
+    "outliers": lambda rng, n: np.concatenate([rng.normal(size=(n - 7, 3)) * 0.1, rng.normal(size=(7, 3)) * 500.0], 0),
+    "duplicates": lambda rng, n: np.repeat(rng.random((n // 4, 3)), 4, axis=0),
+    "sfm_like": lambda rng, n: rng.standard_cauchy((n, 3)).clip(-200, 200),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", sorted(CLOUDS))
+@pytest.mark.parametrize("n", [5, 64, 1000, 20011])
+def test_hip_knn_matches_oracle(kind, n):
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(hash((kind, n)) % 2**32)
+    p = CLOUDS[kind](rng, max(n, 8) if kind in ("outliers", "duplicates") else n).astype(np.float32)
+    got = distCUDA2(torch.tensor(p, device="cuda:0")).cpu().numpy()
+    want = KO.dist_cuda2(p)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-12), float(np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+def test_hip_knn_small_and_degenerate_inputs():
+    from simple_knn._C import distCUDA2
+    dev = "cuda:0"
+    assert distCUDA2(torch.zeros(0, 3, device=dev)).shape == (0,)
+    assert torch.isinf(distCUDA2(torch.zeros(1, 3, device=dev))).all()
+    assert torch.isinf(distCUDA2(torch.rand(2, 3, device=dev))).all()
+    three = distCUDA2(torch.rand(3, 3, device=dev))
+    assert torch.isfinite(three).all() and (three > 1e38).all()
+    same = distCUDA2(torch.ones(100, 3, device=dev))                 # all coincident
+    assert torch.equal(same, torch.zeros(100, device=dev))
+    sq = torch.tensor([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], dtype=torch.float32, device=dev)
+    assert torch.allclose(distCUDA2(sq), torch.full((4,), 4.0 / 3.0, device=dev))
+
+
+@pytest.mark.gpu
+def test_hip_knn_reference_call_pattern_and_scale():
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(1)
+    pts = torch.randn(300000, 3, generator=g)
+    dist2 = torch.clamp_min(distCUDA2(pts.float().cuda()), 0.0000001)      # scene/gaussian_model.py:152-153
+    scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+    assert torch.isfinite(scales).all()
+    sub = torch.randperm(300000, generator=g)[:200]
+    p = pts.numpy().astype(np.float64)
+    want = np.array([np.sort(((p - p[i]) ** 2).sum(1))[1:4].mean() for i in sub.numpy()])
+    assert np.allclose(dist2.cpu().numpy()[sub.numpy()], want, rtol=1e-5)
