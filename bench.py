@@ -71,11 +71,11 @@ def algorithmic_bytes(N, V, R, P, M):
         "scan": 8 * N,
         "duplicate": 8 * R,
         "sort": 16 * R,
-        "finalize_bins": 20 * R,
-        "blend_fwd": 40 * R + 20 * P,
-        "blend_fwd_count": 40 * R + 20 * P + 8 * N,
+        "tile_ranges": 8 * R,
+        "blend_fwd": 44 * R + 20 * P,                 # entry 8 (sorted key) + record 36 per instance
+        "blend_fwd_count": 44 * R + 20 * P + 8 * N,
         "score": 12 * N,
-        "blend_bwd": 88 * R + 20 * P,
+        "blend_bwd": 104 * R + 20 * P,                # entry 8 + rect 16 + record 36 + gradient row 44
         "preprocess_bwd": (108 + 12 * M) * V + (56 + 12 * M) * N + 52 * R,
         "loss_fwd": 3 * P * (8 + 12),   # read image + gt, write the three partial-derivative maps (per channel-pixel)
         "loss_bwd": 3 * P * (12 + 8 + 4),

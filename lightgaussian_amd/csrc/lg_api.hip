@@ -4,7 +4,7 @@
 //   lg_host.h        error strings, optional hipEvent profiler, scratch carving (GeomView / ImgView / BinView)
 //   lg_wave.h        wave64 primitives (DPP / permlane reductions)
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
-//   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_finalize_bins   (per instance; K2/K4 = rocPRIM scan / radix sort)
+//   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_tile_ranges, lg_tile_order (per instance; K2/K4 = rocPRIM scan / radix sort)
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
@@ -133,40 +133,38 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (binning_out) *binning_out = bin_p;
     BinView bin = carve_bin(bin_p, R, W, H, packed);
     HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
-    const uint32_t* point_list = bin.point_list;
+    const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     if (R > 0) {
         {
             ProfScope ps(prof, "duplicate", stream);
             if (packed)
                 lg_duplicate<true><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, depth_bits, gid_bits, geo.touched, geo.offsets, geo.tinfo,
-                                                                        bin.keys_in, nullptr, nullptr);
+                                                                        bin.keys_in, nullptr);
             else
                 lg_duplicate<false><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, 0, 0, geo.touched, geo.offsets, geo.tinfo, bin.keys_in,
-                                                                         bin.slot_in, bin.gid_slot);
+                                                                         bin.vals_in);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
             if (packed)
-                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.keys_out, (unsigned)R, (unsigned)gid_bits,
+                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (unsigned)R, (unsigned)gid_bits,
                                      (unsigned)(gid_bits + depth_bits + tile_bits), stream));
             else
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_out, bin.slot_in, bin.slot_out, (int)R, 0,
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_tmp, bin.vals_in, bin.vals_out, (int)R, 0,
                                                            32 + tile_bits, stream));
         }
         {
-            ProfScope ps(prof, "finalize_bins", stream);
+            ProfScope ps(prof, "tile_ranges", stream);
             if (packed)
-                lg_finalize_bins<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, depth_bits, gid_bits, bin.keys_out,
-                                                                                        geo.tinfo, nullptr, nullptr, bin.point_list,
-                                                                                        bin.slot_out, bin.ranges);
+                lg_tile_ranges<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, depth_bits + gid_bits, bin.entries, nullptr,
+                                                                                      nullptr, bin.ranges);
             else
-                lg_finalize_bins<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, gx, 0, 0, bin.keys_out, geo.tinfo,
-                                                                                         bin.slot_out, bin.gid_slot, bin.point_list,
-                                                                                         bin.slot_out, bin.ranges);
+                lg_tile_ranges<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, 32, bin.keys_tmp, bin.vals_out, bin.entries,
+                                                                                       bin.ranges);
         }
-        KCHECK("lg_finalize_bins");
+        KCHECK("lg_tile_ranges");
     }
     if (count && N > 0) {
         HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
@@ -176,7 +174,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         dim3 grid(ntiles_pad), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
-    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, point_list, geo.rec, v->bg,     \
+    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
@@ -231,6 +229,8 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
+    const int gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));          // same field width as the forward used
+    const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     if (R > 0) {
         // dispatch order of the per-tile backward (longest lists first).  Computed here, not in the forward, so that
@@ -243,10 +243,10 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
-            lg_blend_bwd<false><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<false><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
                                                                  img.final_T, img.n_contrib, dL_dcolor, rows);
         else
-            lg_blend_bwd<true><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.point_list, bin.slot_out, geo.rec, v->bg,
+            lg_blend_bwd<true><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
                                                                 img.final_T, img.n_contrib, dL_dcolor, rows);
     }
     KCHECK("lg_blend_bwd");

@@ -1,4 +1,4 @@
-// lg_binning.h -- binning kernels: depth-maximum reduction, K3 lg_duplicate (packed / pair keys), K5 lg_finalize_bins
+// lg_binning.h -- binning kernels: depth-maximum reduction, K3 lg_duplicate (packed / pair keys), K5 lg_tile_ranges, lg_tile_order
 // Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
 #pragma once
 
@@ -27,13 +27,13 @@ lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, uint32_t* __rest
 // Key formats.  PACKED: tile | (depth bits - bias) | Gaussian id in one u64, sorted keys-only on the tile+depth
 // bits: the stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free
 // (5 passes x 16 B instead of 6 x 24 B).  PAIRS (fallback when the fields do not fit 64 bits): tile<<32 | depth
-// with the pre-sort slot as value.
+// with the Gaussian id as value.
 #define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
 
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
 lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ slots, uint32_t* __restrict__ gid_slot)
+             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -42,8 +42,8 @@ lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __rest
     uint32_t off = offsets[i] - t;
     const uint4 r = tinfo[i];
     const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+    tinfo[i].w = off; // slot base of this Gaussian's instances (lg_slot_of: row address in the backward)
     if (PACKED) {
-        tinfo[i].w = off; // slot base, read back by lg_finalize_bins
         const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
         const int sh = depth_bits + gid_bits;
         for (int y = y0; y < y1; y++)
@@ -53,38 +53,34 @@ lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __rest
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
                 keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
-                slots[off] = off;
-                gid_slot[off] = (uint32_t)i;
+                vals[off] = (uint32_t)i;
                 off++;
             }
     }
 }
 
-// K5: per sorted position: tile ranges, Gaussian id (point_list) and pre-sort slot
+// Pre-sort slot of the instance of Gaussian `gid` in tile (tx, ty): lg_duplicate emits a Gaussian's instances row by row
+// over its tile rectangle starting at tinfo.w, so the slot is a closed form of the rectangle -- no slot array is stored.
+__device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
+{
+    const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF;
+    return r.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+}
+
+// K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised in the packed
+// format -- the blend kernels read the sorted keys themselves).  Pairs format: also writes entries[i] = Gaussian id.
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_finalize_bins(uint32_t R, int gx, int depth_bits, int gid_bits, const uint64_t* __restrict__ keys, const uint4* __restrict__ tinfo,
-                 const uint32_t* __restrict__ slot_sorted, const uint32_t* __restrict__ gid_slot, uint32_t* __restrict__ point_list,
-                 uint32_t* __restrict__ slot_out, uint2* __restrict__ ranges)
+lg_tile_ranges(uint32_t R, int tile_shift, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals_sorted,
+               uint64_t* __restrict__ entries, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
-    const int tsh = PACKED ? depth_bits + gid_bits : 32;
-    const uint64_t key = keys[i];
-    const uint32_t t = (uint32_t)(key >> tsh);
-    if (PACKED) {
-        const uint32_t gid = (uint32_t)(key & ((1ull << gid_bits) - 1ull));
-        const uint4 r = tinfo[gid];
-        const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF;
-        const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
-        point_list[i] = gid;
-        slot_out[i] = r.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    } else {
-        point_list[i] = gid_slot[slot_sorted[i]]; // slot_out was written by the sort itself
-    }
+    const uint32_t t = (uint32_t)(keys[i] >> tile_shift);
+    if (!PACKED) entries[i] = (uint64_t)vals_sorted[i];
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t tp = (uint32_t)(keys[i - 1] >> tsh);
+        const uint32_t tp = (uint32_t)(keys[i - 1] >> tile_shift);
         if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
     }
     if (i == R - 1) ranges[t].y = R;

@@ -4,6 +4,7 @@
 
 #include "lg_host.h"
 #include "lg_wave.h"
+#include "lg_binning.h" // lg_slot_of
 
 // ------------------------------------------------------------------------------------------------
 // tile <-> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).
@@ -71,7 +72,7 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
 template <bool COUNT, bool FSCORE, bool EXACT>
 __global__ void __launch_bounds__(256)
 lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, const float* __restrict__ bg,
+             const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
 {
@@ -100,7 +101,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         bool hit = false;
         float4 r0, r1, r2;
         if (idx < range.y) {
-            const uint32_t id = point_list[idx];
+            const uint32_t id = (uint32_t)entries[idx] & gid_mask;
             r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
             // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
             hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
@@ -302,7 +303,7 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
 lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_sorted, const float4* __restrict__ rec,
+             const uint64_t* __restrict__ entries, uint32_t gid_mask, const uint4* __restrict__ tinfo, const float4* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dpix, float* __restrict__ part)
 {
@@ -352,10 +353,17 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
         const uint32_t nbt = min((uint32_t)LG_Q, n_list - (uint32_t)k * LG_Q);                             // entries of this batch
         const uint32_t nb = wmax > (uint32_t)k * LG_Q ? min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q) : 0u; // ... that any pixel reached
         uint64_t hitmask = 0;
+        // lane <-> list entry base + lane for the whole batch: its Gaussian id (low field of the sorted key) and, issued
+        // here so that the gather completes behind the blending below, its tile rectangle for the row address
+        uint32_t id = 0;
+        uint4 trect = make_uint4(0, 0, 0, 0);
+        if (lane < nbt) {
+            id = (uint32_t)entries[base + lane] & gid_mask;
+            trect = tinfo[id];
+        }
         if (nb > 0) {
             float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
             if (lane < nb) {
-                const uint32_t id = point_list[base + lane];
                 r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
                 uint32_t m = 0;
 #pragma unroll
@@ -404,7 +412,7 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
                 o1 = make_float4(src[4], src[5], src[6], src[7]);
                 o2 = make_float4(src[8], 0.0f, 0.0f, 0.0f);
             }
-            float4* dst = rows + 3 * (size_t)slot_sorted[base + lane];
+            float4* dst = rows + 3 * (size_t)lg_slot_of(trect, tx, ty);
             dst[0] = o0; dst[1] = o1; dst[2] = o2;
         }
         __builtin_amdgcn_wave_barrier();

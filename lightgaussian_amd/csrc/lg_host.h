@@ -152,15 +152,16 @@ static ImgView carve_img(void* base, int W, int H)
 }
 
 // Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
-// offsets for both key formats.
+// offsets for both key formats.  There is no separate id list and no slot list: the id is the low field of the sorted
+// key, and the pre-sort slot (row address of the backward) is recomputed from the Gaussian's tile rectangle (tinfo).
 struct BinView {
     uint2* ranges;                  // [tiles]
-    uint32_t* tile_order;           // [tiles] tile indices, longest list first (dispatch order of the per-tile kernels)
-    uint32_t* point_list;           // [R] Gaussian ids in (tile, depth, id) order
-    uint32_t* slot_out;             // [R] pre-sort slot of every sorted position (row address of the backward)
-    uint64_t *keys_in, *keys_out;   // [R] radix-sort double buffer
-    uint32_t* slot_in;              // [R] (pairs format only) iota values carried through the sort
-    uint32_t* gid_slot;             // [R] (pairs format only) Gaussian id of every pre-sort slot
+    uint32_t* tile_order;           // [tiles] tile indices, longest list first (dispatch order of the backward)
+    uint64_t* entries;              // [R] sorted list entries; the low bits_for(N) bits are the Gaussian id.  Packed format:
+                                    //     these ARE the sorted keys (tile | depth | id).  Pairs format: written by lg_tile_ranges
+    uint64_t* keys_in;              // [R] radix-sort input
+    uint64_t* keys_tmp;             // [R] (pairs format only) sorted keys
+    uint32_t *vals_in, *vals_out;   // [R] (pairs format only) Gaussian ids carried through the sort
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
 static int bits_for(uint32_t n) // smallest b with 2^b >= n
@@ -177,16 +178,15 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
     v.tile_order = (uint32_t*)take((size_t)gx * gy * 4);
-    v.point_list = (uint32_t*)take(n * 4);
-    v.slot_out = (uint32_t*)take(n * 4);
+    v.entries = (uint64_t*)take(n * 8);
     v.keys_in = (uint64_t*)take(n * 8);
-    v.keys_out = (uint64_t*)take(n * 8);
     size_t tb = 0;
     if (packed) {
         (void)lg_sort_keys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)n, 0, 64, nullptr);
     } else {
-        v.slot_in = (uint32_t*)take(n * 4);
-        v.gid_slot = (uint32_t*)take(n * 4);
+        v.keys_tmp = (uint64_t*)take(n * 8);
+        v.vals_in = (uint32_t*)take(n * 4);
+        v.vals_out = (uint32_t*)take(n * 4);
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                                  (uint32_t*)nullptr, (int)n, 0, 64);
     }
