@@ -127,6 +127,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const uint32_t dspan = h_counters[2] > LG_DEPTH_BIAS ? h_counters[2] - LG_DEPTH_BIAS : 0u;
     const int depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
     const bool packed = (tile_bits + depth_bits + gid_bits <= 64) && (getenv("LG_FORCE_PAIR_SORT") == nullptr);
+    // the radix sort works in 8-bit passes: when the tile + depth field is a few bits over a multiple of 8, those lowest
+    // depth bits are left to lg_tile_ranges (runs of equal sorted bits are finished by insertion) and a whole pass is saved
+    int drop = (tile_bits + depth_bits) % 8;
+    if (!packed || depth_bits - drop < 12 || getenv("LG_SORT_ALL_BITS") != nullptr) drop = 0;
 
     void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, packed).total);
     if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
@@ -149,7 +153,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
             if (packed)
-                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (unsigned)R, (unsigned)gid_bits,
+                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (unsigned)R, (unsigned)(gid_bits + drop),
                                      (unsigned)(gid_bits + depth_bits + tile_bits), stream));
             else
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_tmp, bin.vals_in, bin.vals_out, (int)R, 0,
@@ -158,11 +162,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         {
             ProfScope ps(prof, "tile_ranges", stream);
             if (packed)
-                lg_tile_ranges<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, depth_bits + gid_bits, bin.entries, nullptr,
-                                                                                      nullptr, bin.ranges);
+                lg_tile_ranges<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, depth_bits + gid_bits, gid_bits, drop,
+                                                                                      bin.entries, nullptr, bin.entries, bin.ranges);
             else
-                lg_tile_ranges<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, 32, bin.keys_tmp, bin.vals_out, bin.entries,
-                                                                                       bin.ranges);
+                lg_tile_ranges<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, 32, 0, 0, bin.keys_tmp, bin.vals_out,
+                                                                                       bin.entries, bin.ranges);
         }
         KCHECK("lg_tile_ranges");
     }

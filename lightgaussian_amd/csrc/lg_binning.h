@@ -69,21 +69,44 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
 
 // K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised in the packed
 // format -- the blend kernels read the sorted keys themselves).  Pairs format: also writes entries[i] = Gaussian id.
+//
+// DROP > 0 (packed format only): the radix sort skipped the lowest `drop` depth bits to save a whole 8-bit pass
+// (39 -> 32 sorted bits at C3: 5 -> 4 passes).  Entries that agree on the sorted bits form short runs (depth agrees to
+// 2^-16 relative within one tile: about one pair per tile) which are still in emission order; the first thread of each
+// run finishes the job with a stable insertion sort on the full tile | depth field, in place.  The result is exactly the
+// order a sort over all bits gives (stable => id order among equal depths).  Other threads may read a key of the run
+// while it moves: they only look at its tile field, which all members share.
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_tile_ranges(uint32_t R, int tile_shift, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals_sorted,
-               uint64_t* __restrict__ entries, uint2* __restrict__ ranges)
+lg_tile_ranges(uint32_t R, int tile_shift, int gid_bits, int drop, const uint64_t* keys /* == entries in the packed format */,
+               const uint32_t* __restrict__ vals_sorted, uint64_t* entries, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
-    const uint32_t t = (uint32_t)(keys[i] >> tile_shift);
+    const uint64_t key = keys[i];
+    const uint32_t t = (uint32_t)(key >> tile_shift);
     if (!PACKED) entries[i] = (uint64_t)vals_sorted[i];
+    uint64_t prev = 0;
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t tp = (uint32_t)(keys[i - 1] >> tile_shift);
+        prev = keys[i - 1];
+        const uint32_t tp = (uint32_t)(prev >> tile_shift);
         if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
     }
     if (i == R - 1) ranges[t].y = R;
+    if (PACKED && drop > 0) {
+        const int fs = gid_bits + drop;
+        if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal sorted bits
+            uint32_t e = i + 1;
+            while (e < R && (keys[e] >> fs) == (key >> fs)) e++;
+            for (uint32_t a = i + 1; a < e; a++) {               // stable insertion sort of [i, e) on tile | depth
+                const uint64_t k = entries[a];
+                uint32_t b = a;
+                while (b > i && (entries[b - 1] >> gid_bits) > (k >> gid_bits)) { entries[b] = entries[b - 1]; b--; }
+                if (b != a) entries[b] = k;
+            }
+        }
+    }
 }
 
 

@@ -134,6 +134,36 @@ def test_packed_key_sort_equals_pair_sort_fallback():
         assert np.array_equal(a[1]["grads"][name], b[1]["grads"][name]), name   # rows + fixed-order gather: deterministic
 
 
+@pytest.mark.parametrize("jitter", [0.0, 3e-6, 1e-4])
+def test_sort_with_dropped_depth_bits_gives_the_full_order(jitter):
+    """The radix sort skips the lowest depth bits when that saves an 8-bit pass and lg_tile_ranges finishes runs of
+    equal sorted bits by stable insertion.  A wall of Gaussians at (almost) one depth makes such runs long: hit counts
+    and scores must still be bit-identical to the oracle and to a sort over all bits (LG_SORT_ALL_BITS=1)."""
+    import os
+    import gpu_common
+    N, W, H = 6000, 160, 96
+    g = syn.make_gaussians(N, seed=21, log_scale_mean=math.log(0.05), opacity_mean=-0.5, extent=(2, 1.2, 2))
+    cam = syn.orbit_camera(0, 5, W, H, radius=5.0)
+    # camera 0 sits at (0, 0, -5) looking along +z: put every Gaussian on the plane z = 0 (+ relative jitter)
+    gen = torch.Generator().manual_seed(3)
+    g._xyz[:, 2] = jitter * 5.0 * torch.randn(N, generator=gen)
+    kw = common.scene_kwargs(g, cam, W, H, deg=3, bg=(0.1, 0.2, 0.3), as_torch=True)
+    ref = oracle.forward(count=True, **_np(kw))
+    outs = {}
+    for mode in ("drop", "all"):
+        if mode == "all":
+            os.environ["LG_SORT_ALL_BITS"] = "1"
+        try:
+            outs[mode] = gpu_common.hip_forward_backward(kw, count=True)
+        finally:
+            os.environ.pop("LG_SORT_ALL_BITS", None)
+    for mode, out in outs.items():
+        assert np.array_equal(out["count"], ref.count), mode
+        assert np.array_equal(out["score"].view(np.uint32), ref.score.view(np.uint32)), mode
+        assert np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32)), mode
+    assert int(ref.count.sum()) > 10000
+
+
 def test_gradients_are_run_to_run_deterministic():
     import gpu_common
     gimg = np.random.RandomState(6).randn(3, CASES[1]["H"], CASES[1]["W"]).astype(np.float32)
