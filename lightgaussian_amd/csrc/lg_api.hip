@@ -163,10 +163,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "tile_ranges", stream);
             if (packed)
                 lg_tile_ranges<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, depth_bits + gid_bits, gid_bits, drop,
-                                                                                      bin.entries, nullptr, bin.entries, bin.ranges);
+                                                                                      bin.entries, nullptr, bin.entries, bin.keys_in, bin.ranges);
             else
                 lg_tile_ranges<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, 32, 0, 0, bin.keys_tmp, bin.vals_out,
-                                                                                       bin.entries, bin.ranges);
+                                                                                       bin.entries, nullptr, bin.ranges);
         }
         KCHECK("lg_tile_ranges");
     }

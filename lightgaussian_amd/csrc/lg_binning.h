@@ -73,13 +73,13 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
 // DROP > 0 (packed format only): the radix sort skipped the lowest `drop` depth bits to save a whole 8-bit pass
 // (39 -> 32 sorted bits at C3: 5 -> 4 passes).  Entries that agree on the sorted bits form short runs (depth agrees to
 // 2^-16 relative within one tile: about one pair per tile) which are still in emission order; the first thread of each
-// run finishes the job with a stable insertion sort on the full tile | depth field, in place.  The result is exactly the
+// run finishes the job with a stable insertion sort (merge sort beyond 32 entries) on the full tile | depth field.  The result is exactly the
 // order a sort over all bits gives (stable => id order among equal depths).  Other threads may read a key of the run
 // while it moves: they only look at its tile field, which all members share.
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
 lg_tile_ranges(uint32_t R, int tile_shift, int gid_bits, int drop, const uint64_t* keys /* == entries in the packed format */,
-               const uint32_t* __restrict__ vals_sorted, uint64_t* entries, uint2* __restrict__ ranges)
+               const uint32_t* __restrict__ vals_sorted, uint64_t* entries, uint64_t* scratch, uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
@@ -99,11 +99,32 @@ lg_tile_ranges(uint32_t R, int tile_shift, int gid_bits, int drop, const uint64_
         if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal sorted bits
             uint32_t e = i + 1;
             while (e < R && (keys[e] >> fs) == (key >> fs)) e++;
-            for (uint32_t a = i + 1; a < e; a++) {               // stable insertion sort of [i, e) on tile | depth
-                const uint64_t k = entries[a];
-                uint32_t b = a;
-                while (b > i && (entries[b - 1] >> gid_bits) > (k >> gid_bits)) { entries[b] = entries[b - 1]; b--; }
-                if (b != a) entries[b] = k;
+            if (e - i <= 32u) {
+                for (uint32_t a = i + 1; a < e; a++) {           // stable insertion sort of [i, e) on tile | depth
+                    const uint64_t k = entries[a];
+                    uint32_t b = a;
+                    while (b > i && (entries[b - 1] >> gid_bits) > (k >> gid_bits)) { entries[b] = entries[b - 1]; b--; }
+                    if (b != a) entries[b] = k;
+                }
+            } else {
+                // a long run (a slab of Gaussians within 2^-16 of one depth): bottom-up stable merge sort, O(n log n),
+                // ping-ponging with the same range of the (now free) radix-sort input buffer
+                uint64_t* src = entries; uint64_t* dst = scratch;
+                for (uint32_t w = 1; w < e - i; w <<= 1) {
+                    for (uint32_t lo = i; lo < e; lo += 2 * w) {
+                        const uint32_t mid = min(lo + w, e), hi = min(lo + 2 * w, e);
+                        uint32_t a = lo, b = mid, o = lo;
+                        while (a < mid && b < hi) {
+                            const uint64_t ka = src[a], kb = src[b];
+                            if ((kb >> gid_bits) < (ka >> gid_bits)) { dst[o++] = kb; b++; } else { dst[o++] = ka; a++; }
+                        }
+                        while (a < mid) dst[o++] = src[a++];
+                        while (b < hi) dst[o++] = src[b++];
+                    }
+                    uint64_t* t = src; src = dst; dst = t;
+                }
+                if (src != entries)
+                    for (uint32_t a = i; a < e; a++) entries[a] = src[a];
             }
         }
     }

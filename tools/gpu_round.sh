@@ -14,4 +14,4 @@ try:
 except Exception as e: print('RAW', l[-2000:])
 "
 done
-echo "PYTEST: $(tail -1 gpurun_out/pytest_gpu.log)"; echo "SMOKE: $(tail -1 gpurun_out/smoke.log)"
+echo "PYTEST: $(grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -1)"; echo "SMOKE: $(tail -1 gpurun_out/smoke.log)"
