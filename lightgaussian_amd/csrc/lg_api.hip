@@ -12,9 +12,11 @@
 //
 // Pipeline of one view:
 //   K1 project + EWA + SH->RGB + exact footprint culling  ->  K2 scan of instance counts, blocking read of R
-//   K3 packed keys tile|depth|id  ->  K4 stable keys-only radix sort  ->  K5 tile ranges, ids, gradient-row slots
+//   K3 packed keys tile|depth|id  ->  K4 stable keys-only radix sort (lowest depth bits skipped when that saves a pass)
+//   K5 tile ranges + completion of the skipped bits; the sorted keys ARE the per-tile lists (no id / slot arrays)
 //   K6 front-to-back blend (4 autonomous waves per 16x16 tile, LDS queue, select-based pair step, ballot early exit)
-//   K7 back-to-front replay (1 wave per tile, 4 px/lane, packed permlane reduction, one 48-B gradient row per instance)
+//   K7 back-to-front replay (1 wave per tile, longest lists first, 4 px/lane, packed permlane reduction, one 48-B
+//      gradient row per instance at its pre-sort slot, recomputed from the Gaussian's tile rectangle)
 //   K9 per-Gaussian gather of its contiguous rows + cov2D/cov3D/projection/SH backward
 // Written for wave64; no CUDA compatibility paths.
 #include "lg_host.h"
