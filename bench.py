@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--loss", choices=["l1", "l1_dssim", "l1_dssim_torch"], default="l1",
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
+    ap.add_argument("--count-streams", type=int, default=3, help="--mode count: views in flight per rank (host threads x HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
@@ -194,16 +195,17 @@ def main():
         def cam_list(n):
             return [syn.orbit_camera(k % args.views, args.views, W, H).to(dev) for k in range(n)]
         with torch.no_grad():
-            prune_list_sharded(pc, cam_list(max(args.warmup, 1) * world), pipe, bg, force_collectives=world > 1)
+            prune_list_sharded(pc, cam_list(max(args.warmup, 2) * world), pipe, bg, force_collectives=world > 1, streams=args.count_streams)
         cl = cam_list(args.steps * world)
         barrier()
         t0 = time.perf_counter()
         with torch.no_grad():
-            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1)
+            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1, streams=args.count_streams)
         barrier()
         elapsed = time.perf_counter() - t0
         extra["significance_pass"] = {"views": args.steps * world, "seconds": round(elapsed, 4),
-                                      "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item())}
+                                      "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item()),
+                                      "views_in_flight_per_rank": args.count_streams}
         if rank == 0:
             # the epilogue of config C4 (untimed w.r.t. `value`): calculate_v_imp_score(v_pow=0.1) + prune mask at 66 %,
             # device-resident radix selects (lg_prune_epilogue) next to the reference's torch formulation (2 sorts)

@@ -138,57 +138,108 @@ def shard_bounds(num_views, world_size, rank):
     return (num_views * rank) // world_size, (num_views * (rank + 1)) // world_size
 
 
-def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False):
+def _count_views(seq, lo, hi, gaussians, pipe, background, count_fn, N, ncols, streams):
+    """count_fn over seq[lo:hi].  Returns (count_sum int32 [N], per_view fp32 [hi-lo, ncols]) with per_view[k, :N] the
+    score vector of view lo+k.  With streams > 1 the views are rendered by that many host threads, each on its own HIP
+    stream (ctypes releases the GIL; the library is re-entrant per stream): the VALU-bound blend of one view overlaps the
+    memory-latency-bound projection and the radix sort of another.  Results do not depend on the schedule: counts are
+    integers and every view's scores land in their own row, to be summed in the reference's order afterwards."""
+    dev = gaussians.get_xyz.device
+    nv = max(hi - lo, 0)
+    per_view = torch.zeros((nv, ncols), dtype=torch.float32, device=dev)
+    streams = max(1, min(int(streams), nv)) if nv else 1
+    if streams == 1:
+        count_sum = torch.zeros(N, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            for k in range(nv):
+                pkg = count_fn(seq[lo + k], gaussians, pipe, background)
+                count_sum += pkg["gaussians_count"].detach().to(torch.int32)
+                per_view[k, :N] = pkg["important_score"].detach()
+        return count_sum, per_view
+    import threading
+    main = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+    partial = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(streams)]
+    errors = []
+
+    def work(w):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(pool[w]), torch.no_grad():
+                pool[w].wait_stream(main)                 # the frozen getters / zeroed buffers were produced on `main`
+                for k in range(w, nv, streams):
+                    pkg = count_fn(seq[lo + k], gaussians, pipe, background)
+                    partial[w] += pkg["gaussians_count"].to(torch.int32)
+                    per_view[k, :N] = pkg["important_score"]
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(streams)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for st in pool:
+        main.wait_stream(st)
+    count_sum = partial[0]
+    for p in partial[1:]:
+        count_sum += p
+    return count_sum, per_view
+
+
+def _ordered_sum(rows):
+    """acc = rows[0]; acc += rows[1]; ... : the reference's sequential in-place float adds (prune.py:144-155)."""
+    acc = rows[0].clone()
+    for s in range(1, rows.shape[0]):
+        acc += rows[s]
+    return acc
+
+
+def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False,
+                       streams=3):
     """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same
     Gaussians; returns the same (gaussian_list, imp_list) on every rank.  Without an initialised process
-    group (or at world size 1, unless force_collectives) it is the single-process loop with frozen getters."""
+    group (or at world size 1, unless force_collectives) it is the single-process loop with frozen getters.
+    streams: views in flight per rank (host threads x HIP streams, _count_views); 1 = the plain sequential loop.
+    Measured at C3 on one MI355X: 1 -> 1158, 2 -> 1061, 3 -> 1341, 4 -> 1326 views/s (identical results)."""
     from . import rasterizer
     prev = rasterizer._OPTIONS["skip_color_in_count"]
     rasterizer.set_option("skip_color_in_count", True)   # the pass discards the images: do not read 192 B of SH per Gaussian per view
     try:
-        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives)
+        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams)
     finally:
         rasterizer.set_option("skip_color_in_count", prev)
 
 
-def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives):
-    if not (dist.is_available() and dist.is_initialized()):
-        return prune_list(_FrozenGetters(gaussians), scene, pipe, background, count_fn)
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if world == 1 and not force_collectives:
-        return prune_list(_FrozenGetters(gaussians), scene, pipe, background, count_fn)
+def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams):
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
     if mode not in ("ordered", "allreduce"):
         raise ValueError(f"unknown mode {mode!r}")
     gaussians = _FrozenGetters(gaussians)
     cams = _train_cameras(scene)
     V = len(cams)
     seq = cams[::-1]  # sequence order of the reference loop (pop() from the end)
-    lo, hi = shard_bounds(V, world, rank)
     N = gaussians.get_xyz.shape[0]
     dev = gaussians.get_xyz.device
+    if world == 1 and not (distributed and force_collectives):
+        if not gaussians.get_xyz.is_cuda or streams <= 1 or V < 2:
+            return prune_list(gaussians, scene, pipe, background, count_fn)
+        count_sum, per_view = _count_views(seq, 0, V, gaussians, pipe, background, count_fn, N, N, streams)
+        # prune.py:136-141: the first view's own tensors are the accumulators (count dtype = what the rasterizer returns)
+        return count_sum, _ordered_sum(per_view)
 
-    count_sum = torch.zeros(N, dtype=torch.int32, device=dev)
+    lo, hi = shard_bounds(V, world, rank)
     chunk = (N + world - 1) // world
-    if mode == "ordered":
-        per_view = torch.zeros((max(hi - lo, 0), world * chunk), dtype=torch.float32, device=dev)
-    else:
-        local_score = None
-    with torch.no_grad():
-        for k, s in enumerate(range(lo, hi)):
-            pkg = count_fn(seq[s], gaussians, pipe, background)
-            count_sum += pkg["gaussians_count"].detach().to(torch.int32)
-            sc = pkg["important_score"].detach()
-            if mode == "ordered":
-                per_view[k, :N] = sc
-            else:
-                local_score = sc.clone() if local_score is None else local_score.add_(sc)
-
+    count_sum, per_view = _count_views(seq, lo, hi, gaussians, pipe, background, count_fn, N, world * chunk,
+                                       streams if gaussians.get_xyz.is_cuda else 1)
     dist.all_reduce(count_sum, op=dist.ReduceOp.SUM, group=group)
 
     if mode == "allreduce":
-        if local_score is None:
-            local_score = torch.zeros(N, dtype=torch.float32, device=dev)
+        local_score = _ordered_sum(per_view[:, :N]) if hi > lo else torch.zeros(N, dtype=torch.float32, device=dev)
         dist.all_reduce(local_score, op=dist.ReduceOp.SUM, group=group)
         return count_sum, local_score
 
@@ -198,9 +249,7 @@ def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_f
     sizes_out = [shard_bounds(V, world, r)[1] - shard_bounds(V, world, r)[0] for r in range(world)]
     recv = torch.empty((V, chunk), dtype=torch.float32, device=dev)
     dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=[v_local] * world, group=group)
-    acc = recv[0].clone()
-    for s in range(1, V):  # the reference's sequential in-place float adds
-        acc += recv[s]
+    acc = _ordered_sum(recv)
     gathered = torch.empty(world * chunk, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(gathered, acc, group=group)
     return count_sum, gathered[:N].contiguous()

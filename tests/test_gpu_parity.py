@@ -270,6 +270,23 @@ def test_sharded_prune_pass_collectives_on_rccl():
     assert 0 < int(m.sum()) < 4000
 
 
+@pytest.mark.parametrize("streams", [1, 2, 3, 5])
+def test_significance_pass_with_views_in_flight_equals_the_sequential_loop(streams):
+    """prune_list_sharded renders several views concurrently (host threads x HIP streams); counts are integers and the
+    per-view scores are summed afterwards in the reference's order, so the result is bit-identical to prune_list."""
+    from lightgaussian_amd import prune as lg_prune
+    dev = torch.device("cuda:0")
+    g = syn.make_gaussians(20000, seed=17, log_scale_mean=math.log(0.03), opacity_mean=0.0, extent=(2, 1.2, 2)).to(dev)
+    cams = [syn.orbit_camera(k, 11, 160, 96, radius=5.0).to(dev) for k in range(11)]
+    bg = torch.zeros(3, device=dev)
+    pipe = syn.PipelineParams()
+    with torch.no_grad():
+        c1, s1 = lg_prune.prune_list(g, cams, pipe, bg)
+        c2, s2 = lg_prune.prune_list_sharded(g, cams, pipe, bg, streams=streams)
+    assert torch.equal(c1.to(torch.int32), c2.to(torch.int32)) and torch.equal(s1, s2)
+    assert int(c1.sum()) > 0
+
+
 @pytest.mark.parametrize("deg", [3, 1, 0])
 def test_fused_getters_match_unfused_render(deg):
     """render_fused (activations + cat inside the kernels) vs render() on the same raw parameters:
