@@ -154,6 +154,10 @@ size_t lg_prune_scratch_bytes(int32_t N);
 int lg_prune_epilogue(int32_t N, const float* scaling, const float* imp_list, float v_pow, double prune_percent,
                       float* v_list, uint8_t* mask, float* thresholds, void* scratch, uint32_t flags, void* stream);
 
+/* out[j] = (((rows[0][j] + rows[1][j]) + rows[2][j]) + ...) over V rows of n floats (row pitch row_stride floats): the
+ * sequential in-place float accumulation of per-view scores in prune.py:144-155, in view order, as one launch. */
+int lg_ordered_sum(int32_t V, int64_t n, const float* rows, int64_t row_stride, float* out, void* stream);
+
 /* --- distCUDA2 (first half) -------------------------------------------------------
  * Replaces the reference's simple-knn extension: submodules/simple-knn/spatial.cu:15-27 distCUDA2() ->
  * simple_knn.cu:185-221 SimpleKNN::knn(): mean_dist2[i] = (d0 + d1 + d2) / 3 with d0 <= d1 <= d2 the three smallest

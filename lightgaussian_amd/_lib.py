@@ -25,7 +25,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
            "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9", "lg_loss_state_bytes",
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
-           "lg_knn3_mean_dist2"]
+           "lg_knn3_mean_dist2", "lg_ordered_sum"]
 
 
 class lg_view(C.Structure):
@@ -98,6 +98,8 @@ def load():
     lib.lg_knn_scratch_bytes.restype = C.c_size_t; lib.lg_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.lg_knn3_mean_dist2.restype = C.c_int
     lib.lg_knn3_mean_dist2.argtypes = [C.c_int32, vp, vp, vp, C.c_uint32, vp]
+    lib.lg_ordered_sum.restype = C.c_int
+    lib.lg_ordered_sum.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []

@@ -320,6 +320,18 @@ extern "C" int lg_prune_epilogue(int32_t N, const float* scaling, const float* i
     return LG_OK;
 }
 
+extern "C" int lg_ordered_sum(int32_t V, int64_t n, const float* rows, int64_t row_stride, float* out, void* stream_p)
+{
+    if (V <= 0 || n < 0 || row_stride < n) return fail(LG_ERR_INVALID_ARGUMENT, "bad shape");
+    if (n == 0) return LG_OK;
+    if (!rows || !out) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    lg_ordered_sum_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(V, (size_t)n, rows, (size_t)row_stride, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_ordered_sum_kernel launch", e);
+    return LG_OK;
+}
+
 extern "C" size_t lg_knn_scratch_bytes(int32_t P) { return P < 0 ? 0 : carve_knn(nullptr, P).total; }
 
 extern "C" int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* scratch, uint32_t flags, void* stream_p)

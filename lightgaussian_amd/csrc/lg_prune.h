@@ -124,3 +124,15 @@ lg_prune_mask_kernel(int N, uint32_t rank_score, const float* __restrict__ v_lis
     if (blockIdx.x == 0 && threadIdx.x == 0) thresholds[1] = thr;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) mask[i] = v_list[i] <= thr ? 1 : 0;
 }
+
+// out[j] = ((rows[0][j] + rows[1][j]) + rows[2][j]) + ... : the reference's sequential in-place float adds over the views
+// (prune.py:144-155), one launch instead of V - 1 elementwise kernels.  Thread per column, rows streamed coalesced.
+__global__ void __launch_bounds__(256)
+lg_ordered_sum_kernel(int V, size_t n, const float* __restrict__ rows, size_t row_stride, float* __restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float acc = rows[j];
+    for (int v = 1; v < V; v++) acc += rows[(size_t)v * row_stride + j];
+    out[j] = acc;
+}

@@ -190,7 +190,15 @@ def _count_views(seq, lo, hi, gaussians, pipe, background, count_fn, N, ncols, s
 
 
 def _ordered_sum(rows):
-    """acc = rows[0]; acc += rows[1]; ... : the reference's sequential in-place float adds (prune.py:144-155)."""
+    """acc = rows[0]; acc += rows[1]; ... : the reference's sequential in-place float adds (prune.py:144-155).
+    On the GPU one lg_ordered_sum launch (same additions, same order); CPU tensors (gloo tests) take the literal loop."""
+    if rows.is_cuda and rows.dtype == torch.float32 and rows.stride(1) == 1:
+        import ctypes as C
+        from . import _lib
+        out = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
+        _lib.check(_lib.load().lg_ordered_sum(rows.shape[0], rows.shape[1], rows.data_ptr(), rows.stride(0), out.data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)))
+        return out
     acc = rows[0].clone()
     for s in range(1, rows.shape[0]):
         acc += rows[s]
