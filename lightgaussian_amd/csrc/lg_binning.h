@@ -6,9 +6,9 @@
 #include "lg_wave.h"
 
 // ------------------------------------------------------------------------------------------------
-// max over the per-workgroup depth maxima -> counters[2]
+// max over the per-workgroup depth maxima -> counters[2]; instance count of the view (last element of the scan) -> counters[3]
 __global__ void __launch_bounds__(1024)
-lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ counters)
+lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, const uint32_t* __restrict__ last_offset, uint32_t* __restrict__ counters)
 {
     __shared__ uint32_t wmax[16];
     uint32_t m = 0;
@@ -20,6 +20,7 @@ lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, uint32_t* __rest
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
         counters[2] = m;
+        counters[3] = last_offset[0];
     }
 }
 
