@@ -5,6 +5,10 @@ run() { timeout 600 python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | pyth
 import sys, json
 d=json.loads(sys.stdin.read().strip()); c=d['config']; print('$*', '->', d['value'], 'views/s', d['ms_per_step'], 'ms', 'V', c['visible_gaussians'], 'R', c['tile_instances'], d.get('kernels_ms'))"; }
 run --n-gaussians 1000000 --mode fwd --steps 100
+run --n-gaussians 3000000 --mode fwd --steps 100
+run --n-gaussians 3000000 --mode fwdbwd --steps 100
+run --n-gaussians 3000000 --mode count --steps 100
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --no-fuse
 run --n-gaussians 1000000 --mode fwdbwd --steps 100
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
 run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim --no-literal
