@@ -58,6 +58,9 @@ def parse():
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
     ap.add_argument("--count-streams", type=int, default=3, help="--mode count: views in flight per rank (host threads x HIP streams)")
+    ap.add_argument("--views-in-flight", type=int, default=1,
+                    help="fwdbwd/fwd: render this many independent views concurrently (host threads x HIP streams, gradients "
+                         "accumulated per thread as in a camera batch > 1); 1 = the reference's one view per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
@@ -183,6 +186,43 @@ def main():
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
 
+    def make_batch_runner(K):
+        """camera batch > 1: K independent views in flight, each host thread with its own HIP stream and its
+        own parameter replica handles (gradients accumulate per thread; a trainer would sum them before its optimizer step)."""
+        import threading
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        replicas = [pc] + [syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(args.mode == "fwdbwd") for t in params],
+                                                  pc.active_sh_degree, pc.max_sh_degree) for _ in range(K - 1)]
+
+        def run(w, first, count):
+            torch.cuda.set_device(dev)
+            g = replicas[w]
+            gp = [g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
+            with torch.cuda.stream(streams[w]):
+                for i in range(first + w, first + count, K):
+                    k = my_views[i % len(my_views)]
+                    if args.mode == "fwdbwd":
+                        if k not in gts:
+                            k = next(iter(gts))
+                        for p in gp:
+                            p.grad = None
+                        photometric(render(cams[k], g, pipe, bg)["render"], gts[k]).backward()
+                    else:
+                        with torch.no_grad():
+                            render(cams[k], g, pipe, bg)
+
+        def batch(first, count):
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(dev))
+            th = [threading.Thread(target=run, args=(w, first, count)) for w in range(K)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for st in streams:
+                torch.cuda.current_stream(dev).wait_stream(st)
+        return batch
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -223,6 +263,15 @@ def main():
                 ms_torch, m_torch = timed(lambda: _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1)))
             extra["significance_pass"]["epilogue"] = {"hip_ms": round(ms_hip, 4), "torch_ms": round(ms_torch, 4), "pruned": int(m_hip.sum().item()),
                                                       "mask_disagreements_vs_torch": int((m_hip != m_torch).sum().item())}
+    elif args.views_in_flight > 1 and args.mode in ("fwdbwd", "fwd"):
+        batch = make_batch_runner(args.views_in_flight)
+        batch(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        batch(args.warmup, args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        extra["views_in_flight"] = args.views_in_flight
     else:
         for i in range(args.warmup):
             step(i)
@@ -355,6 +404,19 @@ def main():
         result["same_scene_rates_per_gpu"] = {"fwd_views_per_s": round(fwd_rate, 2), "significance_count_views_per_s": round(cnt_rate, 2),
                                               "note": "render() under no_grad; count_render per view as in prune_list_sharded (getters hoisted, "
                                                       "colours skipped); see --mode fwd / --mode count for the full runs"}
+
+    # ---- camera batch of 3: independent views in flight (informational; `value` above is one view per step, as the reference trains) ----
+    if rank == 0 and args.mode in ("fwdbwd", "fwd") and args.views_in_flight == 1 and not args.no_literal:
+        batch3 = make_batch_runner(3)
+        batch3(0, 6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch3(6, 60)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 60
+        result["camera_batch_3"] = {"views_per_s_per_gpu": round(1.0 / dt, 2), "ms_per_view": round(dt * 1e3, 4),
+                                    "note": "three independent views in flight per GPU (host threads x HIP streams, gradient accumulation "
+                                            "semantics): the VALU-bound blend of one view overlaps the memory-bound stages of another"}
 
     # ---- cpu_baseline leg: the oracle on the host cores, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
