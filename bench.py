@@ -191,8 +191,8 @@ def main():
         own parameter replica handles (gradients accumulate per thread; a trainer would sum them before its optimizer step)."""
         import threading
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
-        replicas = [pc] + [syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(args.mode == "fwdbwd") for t in params],
-                                                  pc.active_sh_degree, pc.max_sh_degree) for _ in range(K - 1)]
+        from lightgaussian_amd.parallel import _LeafView
+        replicas = [_LeafView(pc) for _ in range(K)]   # per-thread autograd leaves sharing the parameters' storage (no copies)
 
         def run(w, first, count):
             torch.cuda.set_device(dev)

