@@ -54,8 +54,9 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="force the reference's literal getter pattern (torch exp/sigmoid/normalize/cat "
                     "per render call); default: render() evaluates the getters of a reference GaussianModel inside the kernels")
     ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)  # former opt-in flag; now the default behaviour of render()
-    ap.add_argument("--loss", choices=["l1", "l1_dssim", "l1_dssim_torch"], default="l1",
-                    help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
+    ap.add_argument("--loss", choices=["l1", "l1_torch", "l1_dssim", "l1_dssim_torch"], default="l1",
+                    help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3; HIP lg_loss_forward with LG_FLAG_L1_ONLY), l1_torch (the same "
+                         "in torch ops), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
     ap.add_argument("--count-streams", type=int, default=3, help="--mode count: views in flight per rank (host threads x HIP streams)")
     ap.add_argument("--views-in-flight", type=int, default=1,
@@ -154,6 +155,9 @@ def main():
 
     def photometric(image, gt):
         if args.loss == "l1":
+            from lightgaussian_amd import loss_utils
+            return loss_utils.l1_loss_only(image, gt)
+        if args.loss == "l1_torch":
             return (image - gt).abs().mean()
         if args.loss == "l1_dssim":
             from lightgaussian_amd import loss_utils
@@ -306,7 +310,7 @@ def main():
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
                        "getters": "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
                                   "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
-                       "loss": {"l1": "L1 (torch)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
+                       "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
                        "parallelism": f"camera-shard x{world}"},
         }

@@ -53,6 +53,8 @@ enum {
     LG_FLAG_PROFILE = 4,   /* record per-kernel hipEvent timings, read back with lg_profile_read() */
     LG_FLAG_SKIP_COLOR = 16, /* significance-only forward: K1 does not read the SH rows (colours = 0, the image is meaningless);
                               counts, scores and radii are unaffected.  Used by the sharded prune pass, which discards the image. */
+    LG_FLAG_L1_ONLY = 32,  /* lg_loss_forward / lg_loss_backward only: mean |img - gt| without the SSIM work (out[1] = 0);
+                              forward and backward must agree */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc
@@ -175,7 +177,7 @@ int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
  * out_l1_ssim: device float[2] = {mean |img-gt|, mean ssim_map}.
  * backward: dL_dimg [C,H,W] = scale_l1 * *dL_dl1 * d l1/d img + scale_ssim * *dL_dssim * d ssim/d img; dL_dl1 / dL_dssim are
  * DEVICE scalars (the autograd gradients; NULL => that term is 0), so the call never synchronises.
- * flags: LG_FLAG_DEBUG, LG_FLAG_PROFILE. */
+ * flags: LG_FLAG_DEBUG, LG_FLAG_PROFILE, LG_FLAG_L1_ONLY. */
 size_t lg_loss_state_bytes(int32_t C, int32_t H, int32_t W);
 int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, void* state, float* out_l1_ssim,
                     uint32_t flags, void* stream);

@@ -88,14 +88,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (num_rendered) *num_rendered = 0;
     uint32_t h_counters[3] = {0, 0, 0}, h_R = 0;
     if (N > 0) {
-        HIP_TRY(hipMemsetAsync(geo.counters, 0, 64, stream));
         {
             ProfScope ps(prof, "preprocess", stream);
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
     lg_preprocess<RAWP, DIR><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,      \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
-                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii)
+                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score)
             // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
             const bool direct = getenv("LG_K1_LDS") == nullptr;
             const bool raw = v->flags & LG_FLAG_RAW_PARAMS;
@@ -146,17 +145,17 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
     if (binning_out) *binning_out = bin_p;
     BinView bin = carve_bin(bin_p, R, W, H, packed);
-    HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
+    if (R == 0) HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
     const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     if (R > 0) {
         {
             ProfScope ps(prof, "duplicate", stream);
             if (packed)
                 lg_duplicate<true><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, depth_bits, gid_bits, geo.touched, geo.offsets, geo.tinfo,
-                                                                        bin.keys_in, nullptr);
+                                                                        bin.keys_in, nullptr, ntiles, bin.ranges);
             else
                 lg_duplicate<false><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, 0, 0, geo.touched, geo.offsets, geo.tinfo, bin.keys_in,
-                                                                         bin.vals_in);
+                                                                         bin.vals_in, ntiles, bin.ranges);
         }
         KCHECK("lg_duplicate");
         {
@@ -180,10 +179,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_tile_ranges");
     }
-    if (count && N > 0) {
-        HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)N * 4, stream));
-        HIP_TRY(hipMemsetAsync(out_score, 0, (size_t)N * 4, stream));
-    }
+    // (count / score accumulators of the count variant were cleared by lg_preprocess)
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         dim3 grid(ntiles_pad), block(256);
@@ -393,6 +389,16 @@ extern "C" int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img
     LossView lv = carve_loss(state, C, H, W);
     dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
     if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    if (flags & LG_FLAG_L1_ONLY) {
+        ProfScope ps(prof, "l1_fwd", stream);
+        const size_t n = (size_t)C * H * W;
+        const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)grid.x * grid.y * grid.z);   // partials has one slot per tile
+        lg_l1_fwd<<<blocks, 256, 0, stream>>>(n, img, gt, lv.partials);
+        KCHECK("lg_l1_fwd");
+        lg_loss_finalize<<<1, 256, 0, stream>>>(blocks, 1.0 / (double)n, lv.partials, out_l1_ssim);
+        KCHECK("lg_loss_finalize");
+        return LG_OK;
+    }
     {
         ProfScope ps(prof, "loss_fwd", stream);
         lg_loss_fwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, lv.partials);
@@ -414,6 +420,13 @@ extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* im
     LossView lv = carve_loss(const_cast<void*>(state), C, H, W);
     dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
     if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
+    if (flags & LG_FLAG_L1_ONLY) {
+        ProfScope ps(prof, "l1_bwd", stream);
+        const size_t n = (size_t)C * H * W;
+        lg_l1_bwd<<<(int)std::min<size_t>((n + 1023) / 1024, 65535 * 16), 256, 0, stream>>>(n, img, gt, dL_dl1, scale_l1 / (float)n, dL_dimg);
+        KCHECK("lg_l1_bwd");
+        return LG_OK;
+    }
     {
         ProfScope ps(prof, "loss_bwd", stream);
         lg_loss_bwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, dL_dl1, scale_l1, dL_dssim, scale_ssim,

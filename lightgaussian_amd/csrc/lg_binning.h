@@ -6,19 +6,23 @@
 #include "lg_wave.h"
 
 // ------------------------------------------------------------------------------------------------
-// max over the per-workgroup depth maxima -> counters[2]; instance count of the view (last element of the scan) -> counters[3]
+// Gathers what the host reads back after the scan into counters[0..3] (every word written: no memset of the counters):
+// [1] = any prefiltered violation (bit 31 of the per-workgroup words), [2] = max over the per-workgroup depth maxima,
+// [3] = instance count of the view (last element of the inclusive scan).
 __global__ void __launch_bounds__(1024)
 lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, const uint32_t* __restrict__ last_offset, uint32_t* __restrict__ counters)
 {
-    __shared__ uint32_t wmax[16];
-    uint32_t m = 0;
-    for (int i = threadIdx.x; i < nblk; i += 1024) m = max(m, blk_dmax[i]);
+    __shared__ uint32_t wmax[16], wflag[16];
+    uint32_t m = 0, f = 0;
+    for (int i = threadIdx.x; i < nblk; i += 1024) { const uint32_t v = blk_dmax[i]; m = max(m, v & 0x7FFFFFFFu); f |= v >> 31; }
 #pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wflag[threadIdx.x >> 6] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
+        for (int w = 1; w < 16; w++) { m = max(m, wmax[w]); f |= wflag[w]; }
+        counters[0] = 0;
+        counters[1] = f;
         counters[2] = m;
         counters[3] = last_offset[0];
     }
@@ -34,9 +38,11 @@ lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, const uint32_t* 
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
 lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int ntiles, uint2* __restrict__ ranges)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // empty tiles keep {0, 0}: cleared here (this kernel runs before the sort) instead of by a memset
+    for (int t = i; t < ntiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
     if (i >= N) return;
     const uint32_t t = touched[i];
     if (t == 0) return;

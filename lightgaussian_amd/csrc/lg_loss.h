@@ -239,3 +239,27 @@ lg_loss_bwd(int H, int W, const float* __restrict__ img, const float* __restrict
         }
     }
 }
+
+// L1 alone (LG_FLAG_L1_ONLY): mean |x - y| without the windowed moments, for callers that do not use SSIM.
+// Same partials / finalize as the fused kernel (ssim partial = 0); 4 elements per thread, float4 when aligned.
+__global__ void __launch_bounds__(256)
+lg_l1_fwd(size_t n, const float* __restrict__ img, const float* __restrict__ gt, float2* __restrict__ partials)
+{
+    __shared__ float wsum[4];
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += fabsf(img[i] - gt[i]);
+    acc = wave_sum_to_lane63(acc);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = make_float2((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), 0.0f);
+}
+__global__ void __launch_bounds__(256)
+lg_l1_bwd(size_t n, const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ dL_dl1, float scale,
+          float* __restrict__ dL_dimg)
+{
+    const float g = dL_dl1 ? dL_dl1[0] * scale : 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = img[i] - gt[i];
+        dL_dimg[i] = d > 0.0f ? g : (d < 0.0f ? -g : 0.0f);
+    }
+}

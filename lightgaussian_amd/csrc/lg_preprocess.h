@@ -70,7 +70,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
               const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
               const float* __restrict__ colors_precomp,
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
-              const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii)
+              const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii, int32_t* __restrict__ zero_count,
+              float* __restrict__ zero_score)
 {
     // DIRECT (default): every visible lane reads its own SH row with dwordx4 loads (read_row_direct) and no LDS is
     // allocated for SH (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3).  The LDS-staged
@@ -85,7 +86,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    bool vis = false;
+    bool vis = false, violation = false;
     float px = 0, py = 0, pz = 0, op = 0;
     float cov[6] = {0, 0, 0, 0, 0, 0};
     LgSplat sp;
@@ -112,8 +113,10 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
             op = RAW ? lg_sigmoid(opacities[i]) : opacities[i];
             vis = lg_project(vm, pm, px, py, pz, cov, op, W, H, tanfovx, tanfovy, sp);
         } else if (prefiltered) {
-            g.counters[1] = 1u;
+            violation = true;   // "Point is filtered although prefiltered is set": reported through the per-workgroup word below
         }
+        // the count variant accumulates into these with atomics from the blend kernel: cleared here instead of by two memsets
+        if (zero_count) { zero_count[i] = 0; zero_score[i] = 0.0f; }
     }
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;        // dc and rest are separate tensors
@@ -194,7 +197,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     uint32_t dmax = vis ? __float_as_uint(sp.depth) : 0u;
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, sh));
-    if (lane == 0) g.blk_dmax[blockIdx.x] = dmax;
+    // bit 31 (never set in the bit pattern of a positive depth): a prefiltered violation in this workgroup
+    if (lane == 0) g.blk_dmax[blockIdx.x] = dmax | (__ballot(violation) ? 0x80000000u : 0u);
 }
 
 

@@ -30,14 +30,16 @@ def _flags():
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, gt):
+    def forward(ctx, img, gt, l1_only=False):
         lib = _lib.load()
+        ctx.l1_only = bool(l1_only)
+        flags = _flags() | (_lib.FLAG_L1_ONLY if l1_only else 0)
         H, W = img.shape[-2], img.shape[-1]
         planes = img.numel() // (H * W)
         state = torch.empty(lib.lg_loss_state_bytes(planes, H, W), dtype=torch.uint8, device=img.device)
         out = torch.empty(2, dtype=torch.float32, device=img.device)
         stream = torch.cuda.current_stream(img.device).cuda_stream
-        _lib.check(lib.lg_loss_forward(planes, H, W, img.data_ptr(), gt.data_ptr(), state.data_ptr(), out.data_ptr(), _flags(),
+        _lib.check(lib.lg_loss_forward(planes, H, W, img.data_ptr(), gt.data_ptr(), state.data_ptr(), out.data_ptr(), flags,
                                        C.c_void_p(stream)))
         ctx.save_for_backward(img, gt, state)
         ctx.dims = (planes, H, W)
@@ -54,8 +56,8 @@ class _L1SSIM(torch.autograd.Function):
         _lib.check(lib.lg_loss_backward(planes, H, W, img.data_ptr(), gt.data_ptr(), state.data_ptr(),
                                         None if keep[0] is None else C.c_void_p(keep[0].data_ptr()), 1.0,
                                         None if keep[1] is None else C.c_void_p(keep[1].data_ptr()), 1.0,
-                                        grad.data_ptr(), _flags(), C.c_void_p(stream)))
-        return grad, None
+                                        grad.data_ptr(), _flags() | (_lib.FLAG_L1_ONLY if ctx.l1_only else 0), C.c_void_p(stream)))
+        return grad, None, None
 
 
 def _prep(img, gt):
@@ -88,6 +90,13 @@ def _both(img, gt):
 def l1_loss(network_output, gt):
     """utils/loss_utils.py:18-19: mean |network_output - gt|."""
     return _both(network_output, gt)[0]
+
+
+def l1_loss_only(network_output, gt):
+    """mean |network_output - gt| for callers that never ask for SSIM: one streaming pass, no windowed moments
+    (LG_FLAG_L1_ONLY).  l1_loss() is the right call inside the reference's trainers, which always follow it with ssim()."""
+    a, b = _prep(network_output, gt)
+    return _L1SSIM.apply(a, b, True)[0]
 
 
 def l2_loss(network_output, gt):

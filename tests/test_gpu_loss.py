@@ -85,6 +85,19 @@ def test_identical_images_and_separate_terms():
     assert float(loss) == pytest.approx(LO.l1_dssim(x.cpu().numpy(), y.cpu().numpy(), 0.2), rel=TOL)
 
 
+@pytest.mark.parametrize("shp", [(3, 37, 53), (3, 1080, 1920), (1, 5, 7)])
+def test_l1_only_kernel(shp):
+    """LG_FLAG_L1_ONLY: the streaming L1 kernels give the same value and the same (exact) sign gradient as the fused ones."""
+    rng = np.random.default_rng(11)
+    x = rng.random(shp, dtype=np.float32); y = rng.random(shp, dtype=np.float32)
+    y.flat[::7] = x.flat[::7]                                              # exact ties: gradient 0
+    xt = torch.tensor(x, device=DEV, requires_grad=True); yt = torch.tensor(y, device=DEV)
+    l = LU.l1_loss_only(xt, yt)
+    (3.0 * l).backward()
+    assert float(l.detach()) == pytest.approx(LO.l1_loss(x, y), rel=1e-6)
+    assert np.array_equal(xt.grad.cpu().numpy(), (3.0 * np.sign(x - y) / x.size).astype(np.float32))
+
+
 def test_loss_rejects_cpu_tensors_and_unsupported_options():
     with pytest.raises(RuntimeError):
         LU.l1_loss(torch.rand(3, 8, 8), torch.rand(3, 8, 8))
