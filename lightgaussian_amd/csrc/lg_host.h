@@ -127,17 +127,23 @@ static GeomView carve_geom(void* base, int N)
 #define LG_SORT_BITS 8
 #endif
 #ifdef LG_SORT_ROCPRIM_DEFAULT
+using lg_onesweep_config = rocprim::default_config;
 using lg_sort_config = rocprim::default_config;
 #else
-using lg_sort_config = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>, rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>,
-                                        LG_SORT_BITS, rocprim::block_radix_rank_algorithm::match>>;
+using lg_onesweep_config = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>,
+                                                               rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>, LG_SORT_BITS,
+                                                               rocprim::block_radix_rank_algorithm::match>;
+using lg_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, lg_onesweep_config>;
 #endif
+#include "lg_sort.h"
 static inline hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, uint64_t* keys_in, uint64_t* keys_out, unsigned n, unsigned begin_bit,
                                       unsigned end_bit, hipStream_t stream)
 {
+#ifdef LG_SORT_ROCPRIM_HOST
     return rocprim::radix_sort_keys<lg_sort_config>(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, stream);
+#else
+    return lg_onesweep_sort_keys<lg_onesweep_config>(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, stream);
+#endif
 }
 
 struct ImgView { float* final_T; uint32_t* n_contrib; size_t total; };
