@@ -14,7 +14,14 @@ lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, const uint32_t* 
 {
     __shared__ uint32_t wmax[16], wflag[16];
     uint32_t m = 0, f = 0;
-    for (int i = threadIdx.x; i < nblk; i += 1024) { const uint32_t v = blk_dmax[i]; m = max(m, v & 0x7FFFFFFFu); f |= v >> 31; }
+    // this single block sits on the critical path of the forward's read-back: 16-byte loads (the array is 256-byte aligned)
+    const int nvec = nblk >> 2;
+    for (int i = threadIdx.x; i < nvec; i += 1024) {
+        const uint4 v = reinterpret_cast<const uint4*>(blk_dmax)[i];
+        m = max(max(m, v.x & 0x7FFFFFFFu), max(v.y & 0x7FFFFFFFu, max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu)));
+        f |= (v.x | v.y | v.z | v.w) >> 31;
+    }
+    for (int i = (nvec << 2) + threadIdx.x; i < nblk; i += 1024) { const uint32_t v = blk_dmax[i]; m = max(m, v & 0x7FFFFFFFu); f |= v >> 31; }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
     if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wflag[threadIdx.x >> 6] = f; }
