@@ -51,8 +51,9 @@ enum {
                               canonical path to ~1e-6, far inside the 1e-4 contract; never used for count renders,
                               whose integer outputs are bit-pinned */
     LG_FLAG_PROFILE = 4,   /* record per-kernel hipEvent timings, read back with lg_profile_read() */
-    LG_FLAG_SKIP_COLOR = 16, /* significance-only forward: K1 does not read the SH rows (colours = 0, the image is meaningless);
-                              counts, scores and radii are unaffected.  Used by the sharded prune pass, which discards the image. */
+    LG_FLAG_SKIP_COLOR = 16, /* significance-only forward (lg_forward_count): K1 does not read the SH rows and the blend kernel
+                              neither accumulates colour nor writes out_color / the per-pixel state (their contents are
+                              undefined); counts, scores and radii are unaffected.  Used by the sharded prune pass. */
     LG_FLAG_L1_ONLY = 32,  /* lg_loss_forward / lg_loss_backward only: mean |img - gt| without the SSIM work (out[1] = 0);
                               forward and backward must agree */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the

@@ -187,7 +187,12 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
+        const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
+        else if (nocolor) {
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy);
+        }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
 #undef LAUNCH_FWD

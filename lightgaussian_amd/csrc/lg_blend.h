@@ -44,7 +44,7 @@ __device__ __forceinline__ float guard_alpha(float alpha, float opacity, float p
 
 // Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
 // every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
-template <bool EXACT>
+template <bool EXACT, bool COLOR = true>
 __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
                                          float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out)
 {
@@ -59,8 +59,10 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const bool sat = ok && (test_T < LG_T_MIN);
     const bool contrib = ok && !sat;
     // one select on the weight instead of three on the colours: fmaf(rgb, 0, C) == C bit for bit (finite rgb)
-    const float w = contrib ? alpha * T : 0.0f;
-    C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
+    if (COLOR) {   // significance-only passes (LG_FLAG_SKIP_COLOR) carry no colour at all
+        const float w = contrib ? alpha * T : 0.0f;
+        C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
+    }
     T = contrib ? test_T : T;
     last = contrib ? rel : last;
     done = done || sat;
@@ -69,7 +71,7 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
 }
 
 // K6 / K6c: forward blend
-template <bool COUNT, bool FSCORE, bool EXACT>
+template <bool COUNT, bool FSCORE, bool EXACT, bool COLOR = true>
 __global__ void __launch_bounds__(256)
 lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
@@ -122,7 +124,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             mask &= mask - 1;
             const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
             float alpha = 0.0f, Tprev = T;
-            const int res = fwd_pair<EXACT>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha) ? 1 : 0;
+            const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha) ? 1 : 0;
             if (COUNT) {
                 const uint64_t cm = __ballot(res == 1);
                 if (lane == j) mycnt = (int)__popcll(cm);
@@ -145,7 +147,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (inside) {
+    if (COLOR && inside) {   // !COLOR: forward-only significance pass, nothing per pixel is kept
         const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
         final_T[pid] = T;
         n_contrib[pid] = last;

@@ -49,8 +49,8 @@ def set_option(name, value):
     profile: record per-kernel hipEvent timings (read with _lib.profile_read());
     fuse_getters (default True): gaussian_renderer.render() evaluates the getters of a reference GaussianModel inside the
               kernels (LG_FLAG_RAW_PARAMS) instead of in torch; False = the reference's literal getter pattern;
-    skip_color_in_count: count renders do not evaluate colours (image = background-free zeros); for passes that only
-              consume gaussians_count / important_score, e.g. prune_list_sharded."""
+    skip_color_in_count: count renders do not evaluate colours and do not write the image (the returned `render` tensor is
+              uninitialised memory); for passes that only consume gaussians_count / important_score, e.g. prune_list_sharded."""
     if name not in _OPTIONS:
         raise KeyError(name)
     _OPTIONS[name] = value
