@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Extended seeded fuzz (not part of the test suite: ~1-2 minutes): random scene statistics incl. tiny images, single
+Gaussians, depth slabs (long runs of equal sorted key bits), huge splats; hit counts / scores / radii / count-render image
+bit-identical to the float oracle, training render within 1e-5, gradients within max(1e-4, 3 x fp32-oracle noise floor) of the float64 oracle."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+import gpu_common  # noqa: E402
+from common import syn  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+only = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+bad = 0
+for t in range(trials):
+    rs = np.random.RandomState(777 + 7919 * t)          # per-trial stream: `only` reruns exactly one trial
+    if only >= 0 and t != only:
+        continue
+    N = int(rs.choice([1, 2, 7, 64, 65, 300, 2000, 9000]))
+    W, H = int(rs.choice([1, 5, 16, 17, 33, 100, 257])), int(rs.choice([1, 3, 16, 31, 64, 130]))
+    deg = int(rs.randint(0, 4))
+    scale = float(np.exp(rs.uniform(np.log(0.002), np.log(0.8))))
+    g = syn.make_gaussians(N, sh_degree=deg, seed=1000 + t, log_scale_mean=math.log(scale), opacity_mean=float(rs.uniform(-4, 3)),
+                           extent=(float(rs.uniform(0.3, 3)), float(rs.uniform(0.3, 2)), float(rs.uniform(0.3, 3))), log_scale_std=float(rs.uniform(0.1, 1.2)))
+    cam = syn.orbit_camera(int(rs.randint(0, 8)), 8, W, H, radius=float(rs.uniform(2.5, 7)))
+    if rs.rand() < 0.25:   # depth slab in front of camera 0
+        cam = syn.orbit_camera(0, 8, W, H, radius=5.0)
+        g._xyz[:, 2] = float(rs.choice([0.0, 1e-6, 1e-4])) * torch.randn(N)
+    kw = common.scene_kwargs(g, cam, W, H, deg=deg, bg=tuple(rs.rand(3).astype(np.float32)), as_torch=True)
+    npk = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    ref = oracle.forward(count=True, **npk)
+    out = gpu_common.hip_forward_backward(kw, count=True)
+    why = []
+    if not np.array_equal(out["radii"], ref.radii): why.append("radii")
+    if not np.array_equal(out["count"], ref.count): why.append(f"count({int((out['count'] != ref.count).sum())})")
+    if not np.array_equal(out["score"].view(np.uint32), ref.score.view(np.uint32)): why.append("score")
+    if not np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32)): why.append("count-image")
+    ok = not why
+    gimg = rs.randn(3, H, W).astype(np.float32)
+    fast = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    if np.abs(fast["color"] - ref.color).max() > 1e-5: why.append(f"fast-image({np.abs(fast['color'] - ref.color).max():.2e})")
+    # gradients: against the float64 oracle, tolerance 1e-4 widened to 3x the error the float32 ORACLE itself has against
+    # float64 on these inputs (the T/(1-alpha) replay of the published algorithm amplifies rounding), as tests/ do
+    g32 = oracle.backward(ref, gimg)
+    ref64 = oracle.forward(dtype=np.float64, **npk); g64 = oracle.backward(ref64, gimg)
+    for name, gv in fast["grads"].items():
+        if name in g64 and gv is not None and g64[name] is not None:
+            r = g64[name]
+            floor = gpu_common.rel_err(g32[name], r)
+            e = gpu_common.rel_err(gv.reshape(r.shape), r)
+            if not np.isfinite(gv).all() or e > max(1e-4, 3.0 * floor): why.append(f"grad:{name}(err {e:.2e}, fp32 floor {floor:.2e})")
+    if why and only >= 0:   # diagnosis: the same gradients with the canonical arithmetic (no hardware exp / rcp)
+        from lightgaussian_amd import rasterizer
+        rasterizer.set_option("fast_exp", False)
+        ex = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+        rasterizer.set_option("fast_exp", True)
+        print("   canonical arithmetic:", {n: f"{gpu_common.rel_err(v.reshape(g64[n].shape), g64[n]):.2e}" for n, v in ex["grads"].items() if n in g64 and g64[n] is not None})
+    if why:
+        bad += 1
+        print(f"MISMATCH trial {t}: N={N} {W}x{H} deg={deg} scale={scale:.4f}: {', '.join(why)}")
+print(f"fuzz: {trials} trials, {bad} mismatches")
+sys.exit(1 if bad else 0)
