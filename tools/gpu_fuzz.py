@@ -65,5 +65,42 @@ for t in range(trials):
     if why:
         bad += 1
         print(f"MISMATCH trial {t}: N={N} {W}x{H} deg={deg} scale={scale:.4f}: {', '.join(why)}")
-print(f"fuzz: {trials} trials, {bad} mismatches")
+# ---- phase 2: getters inside the kernels (render_fused, LG_FLAG_RAW_PARAMS) against the literal torch getter pattern ----
+from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused  # noqa: E402
+dev = torch.device("cuda:0")
+bad2 = 0
+n2 = max(10, trials // 4)
+for t in range(n2):
+    rs = np.random.RandomState(991 + 104729 * t)
+    N = int(rs.choice([1, 63, 64, 65, 500, 4099, 20000]))
+    W, H = int(rs.choice([16, 33, 100, 257])), int(rs.choice([16, 31, 64, 130]))
+    deg = int(rs.randint(0, 4))
+    mk = lambda: syn.make_gaussians(N, sh_degree=deg, seed=5000 + t, log_scale_mean=math.log(float(np.exp(rs_scale))), opacity_mean=op_mean,
+                                    extent=(2, 1.2, 2)).to(dev).requires_grad_(True)
+    rs_scale, op_mean = rs.uniform(np.log(0.005), np.log(0.3)), float(rs.uniform(-3, 2))
+    cam = syn.orbit_camera(int(rs.randint(0, 8)), 8, W, H, radius=5.0).to(dev)
+    bg = torch.tensor(rs.rand(3).astype(np.float32), device=dev)
+    gimg = torch.tensor(rs.randn(3, H, W).astype(np.float32), device=dev)
+    res = []
+    for fn in (_render_unfused, render_fused):
+        g = mk()
+        pkg = fn(cam, g, syn.PipelineParams(), bg)
+        (pkg["render"] * gimg).sum().backward()
+        res.append((pkg["render"].detach(), pkg["radii"], [getattr(g, n).grad for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")]))
+    (ia, ra, ga), (ib, rb, gb) = res
+    why = []
+    # radius = ceil(3 sigma): expf in the kernel vs torch.exp can land on different sides of an integer for a Gaussian or two
+    dr = (ra - rb).abs()
+    if int(dr.max()) > 1 or int((dr > 0).sum()) > max(1, N // 5000): why.append(f"radii({int((dr > 0).sum())} differ, max {int(dr.max())})")
+    if float((ia - ib).abs().max()) > 1e-5 * max(float(ia.abs().max()), 1e-6): why.append(f"image({float((ia - ib).abs().max()):.2e})")
+    for n, x, y in zip(("xyz", "dc", "rest", "scaling", "rotation", "opacity"), ga, gb):
+        if x is None or x.numel() == 0:
+            continue
+        e = float((x - y).abs().max()) / max(float(x.abs().max()), 1e-20)
+        if y is None or not torch.isfinite(y).all() or e > 2e-4: why.append(f"grad:{n}({e:.2e})")
+    if why:
+        bad2 += 1
+        print(f"FUSED MISMATCH trial {t}: N={N} {W}x{H} deg={deg}: {', '.join(why)}")
+print(f"fuzz: {trials} trials, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches")
+bad += bad2
 sys.exit(1 if bad else 0)
