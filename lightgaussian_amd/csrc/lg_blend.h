@@ -259,7 +259,9 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
 
 // Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
 // the whole sequence and invalid lanes are neutralised by zeroing dL/dalpha and the colour weight and by
-// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.)
+// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
+// early-out when no lane of the 8x8 block takes the entry -- `if (__ballot(ok) == 0) return` -- was measured: 0.946 vs
+// 0.927 ms; blocks that pass the box test almost always have a contributing pixel.)
 __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
                                               float& T, float T_final, float g0, float g1, float g2, float bg_dot, float& a0, float& a1,
                                               float& a2, float (&p)[9])
