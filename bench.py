@@ -28,7 +28,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+
+import torch  # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
