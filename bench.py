@@ -107,7 +107,7 @@ def main():
 
     from lightgaussian_amd import _lib, synthetic as syn
     from lightgaussian_amd import rasterizer
-    from lightgaussian_amd.gaussian_renderer import render, count_render, render_fused
+    from lightgaussian_amd.gaussian_renderer import render, count_render
     rasterizer.set_option("fuse_getters", not args.no_fuse)
     from lightgaussian_amd.prune import prune_list_sharded
 

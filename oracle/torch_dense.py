@@ -12,7 +12,6 @@ Deliberate matches to the published backward's conventions (not "true" derivativ
 The 1e-7 regulariser in 1/(det^2+1e-7) of the published cov2D backward is NOT reproduced
 (relative effect <= 1.3e-5), so compare at ~1e-4.
 """
-import math
 
 import torch
 

@@ -5,7 +5,6 @@ in this container.  The fixture travels; /root/reference does not.
 """
 import importlib.util
 import os
-import sys
 
 import numpy as np
 import torch
