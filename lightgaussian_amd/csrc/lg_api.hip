@@ -57,6 +57,28 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
     return LG_OK;
 }
 
+// 64-byte pinned host slots for the forward's read-back, recycled through a process-wide free list (a thread_local slot
+// would be allocated -- and leaked -- by every short-lived host thread of the views-in-flight helpers).
+static std::mutex g_pin_mu;
+static std::vector<uint32_t*> g_pin_free;
+struct PinnedSlot {
+    uint32_t* p = nullptr;
+    PinnedSlot()
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            if (!g_pin_free.empty()) { p = g_pin_free.back(); g_pin_free.pop_back(); }
+        }
+        if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    }
+    ~PinnedSlot()
+    {
+        if (p) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_free.push_back(p); }
+    }
+    PinnedSlot(const PinnedSlot&) = delete;
+    PinnedSlot& operator=(const PinnedSlot&) = delete;
+};
+
 #define KCHECK(name)                                                                         \
     do {                                                                                     \
         hipError_t _e = hipGetLastError();                                                   \
@@ -117,12 +139,12 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         // kernel instead of hipStreamSynchronize was measured as well: no difference, so the plain form stays.)
         lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.offsets + (N - 1), geo.counters);
         KCHECK("lg_reduce_dmax");
-        static thread_local uint32_t* h_pinned = nullptr;
-        if (!h_pinned) HIP_TRY(hipHostMalloc((void**)&h_pinned, 64, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(h_pinned, geo.counters, 16, hipMemcpyDeviceToHost, stream));
+        PinnedSlot slot;                                      // process-wide pool: host threads come and go (views in flight)
+        if (!slot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the read-back slot failed");
+        HIP_TRY(hipMemcpyAsync(slot.p, geo.counters, 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        h_counters[0] = h_pinned[0]; h_counters[1] = h_pinned[1]; h_counters[2] = h_pinned[2];
-        h_R = h_pinned[3];
+        h_counters[0] = slot.p[0]; h_counters[1] = slot.p[1]; h_counters[2] = slot.p[2];
+        h_R = slot.p[3];
         if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     }
     const int64_t R = h_R;
