@@ -310,7 +310,8 @@ def main():
                                    f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
-                       "getters": "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
+                       "getters": "evaluated once per pass by torch and reused for every view (prune._FrozenGetters)" if args.mode == "count" else
+                                  "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
                                   "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
                        "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,

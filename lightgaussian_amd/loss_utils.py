@@ -13,6 +13,7 @@ pattern -- runs the kernel once: the second call returns the other output of the
 There is no PyTorch fallback: CPU tensors raise.
 """
 import ctypes as C
+import threading
 import weakref
 
 import torch
@@ -70,20 +71,20 @@ def _prep(img, gt):
     return img.contiguous().float(), gt.detach().contiguous().float()
 
 
-_last = None  # (weakref(img), version, weakref(gt), version, (l1, ssim))
+_memo = threading.local()  # .last = (weakref(img), version, weakref(gt), version, (l1, ssim, grad_mode)); per host thread
 
 
 def _both(img, gt):
     """(l1, ssim) of one fused launch; memoised on tensor identity + version so that the reference's
     l1_loss(image, gt) ... ssim(image, gt) pair costs one forward and one backward launch."""
-    global _last
-    if _last is not None:
-        wi, vi, wg, vg, res = _last
+    last = getattr(_memo, "last", None)
+    if last is not None:
+        wi, vi, wg, vg, res = last
         if wi() is img and wg() is gt and vi == img._version and vg == gt._version and torch.is_grad_enabled() == res[2]:
             return res[0], res[1]
     a, b = _prep(img, gt)
     l1, ss = _L1SSIM.apply(a, b)
-    _last = (weakref.ref(img), img._version, weakref.ref(gt), gt._version, (l1, ss, torch.is_grad_enabled()))
+    _memo.last = (weakref.ref(img), img._version, weakref.ref(gt), gt._version, (l1, ss, torch.is_grad_enabled()))
     return l1, ss
 
 
