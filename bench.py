@@ -68,7 +68,87 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
     ap.add_argument("--cpu-baseline-n", type=int, default=0, help="Gaussians in the CPU sample (0 = same as workload)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend; gloo only with --dry-run (CPU, tests)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launcher, the process group, the camera sharding and the significance reduction on a tiny CPU scene "
+                         "with a synthetic per-view counter (no GPU, no rendering): what tests/test_bench_launcher.py drives at world 2")
+    ap.add_argument("--no-verify-1gpu", action="store_true", help="--mode count, N > 1: skip recomputing the single-rank prune mask on rank 0")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _error_record(args, msg, rc):
+    """One JSON line instead of a traceback when the job cannot start (fewer devices than --gpus, no GPU at all)."""
+    print(json.dumps({"metric": "views/sec fwd+bwd @1080p (N Gaussians)", "value": None, "unit": "views/s", "n_gpus": args.gpus,
+                      "error": msg, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    raise SystemExit(rc)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: re-exec as N ranks under torch.distributed.run (one process per GPU,
+    RCCL over xGMI; rendezvous on 127.0.0.1).  Replaces the reference's scripts/run_prune_finetune.sh:58-96 style of one
+    independent job per GPU."""
+    import subprocess
+    if args.backend == "nccl" and not args.dry_run:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus:
+            _error_record(args, f"--gpus {args.gpus} requested but {ndev} HIP device(s) visible", 3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def mask_digest(mask):
+    """sha256 of the prune mask's bytes (uint8 0/1 per Gaussian): equal digests <=> Hamming distance 0."""
+    import hashlib
+    return hashlib.sha256(mask.detach().to("cpu", torch.uint8).contiguous().numpy().tobytes()).hexdigest()
+
+
+def dry_run(args, rank, world):
+    """Launcher / sharding / reduction check without a GPU: a tiny CPU scene, a synthetic deterministic per-view counter in
+    place of count_render, the real prune_list_sharded (ordered score exchange + integer all-reduce) over `--backend`, the
+    reference's epilogue, and the single-rank recomputation of the mask on rank 0."""
+    from lightgaussian_amd import synthetic as syn
+    from lightgaussian_amd import prune as lg_prune
+    N, V = 4096, max(2, args.steps) * world
+    g = syn.make_gaussians(N, seed=7)
+    cams = [syn.orbit_camera(k % 16, 16, 64, 48) for k in range(V)]
+    for k, c in enumerate(cams):
+        c.uid = k
+
+    def fake_count(cam, pc, pipe, bg):
+        x = pc.get_xyz
+        phase = (x * torch.tensor([12.9898, 78.233, 37.719])).sum(1) + 0.61803 * float(cam.uid + 1)
+        frac = torch.frac(torch.sin(phase) * 43758.5453).abs()
+        cnt = (frac * 9.0).to(torch.int32)
+        return {"gaussians_count": cnt, "important_score": cnt.to(torch.float32) * pc.get_opacity.reshape(-1)}
+
+    pipe, bg = syn.PipelineParams(), torch.zeros(3)
+    t0 = time.perf_counter()
+    cnt, imp = lg_prune.prune_list_sharded(g, cams, pipe, bg, count_fn=fake_count, force_collectives=world > 1, streams=1)
+    mask = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, imp, 0.1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    digest = mask_digest(mask)
+    if rank == 0:
+        c1, i1 = lg_prune.prune_list(g, cams, pipe, bg, count_fn=fake_count)
+        m1 = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, i1, 0.1))
+        print(json.dumps({"metric": "views/sec count (dry run)", "value": round(V / elapsed, 3), "unit": "views/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "backend": args.backend,
+                          "world_size_observed": dist.get_world_size() if world > 1 else 1, "views": V,
+                          "mask_sha256": digest, "mask_equals_1gpu": bool(torch.equal(m1, mask)),
+                          "counts_equal_1gpu": bool(torch.equal(c1, cnt)), "scores_bit_identical_1gpu": bool(torch.equal(i1, imp)),
+                          "pruned": int(mask.sum().item())}), flush=True)
 
 
 def algorithmic_bytes(N, V, R, P, M):
@@ -95,10 +175,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        if "RANK" not in os.environ and args.gpus > 1:
+            self_launch(args)            # bare `python bench.py --gpus N`: become N ranks (does not return)
+        _error_record(args, f"WORLD_SIZE={world} does not match --gpus {args.gpus}", 2)
+    if args.backend == "gloo" and not args.dry_run:
+        _error_record(args, "--backend gloo is for --dry-run only: the rasterizer has no CPU path", 2)
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend)
+        dry_run(args, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+        _error_record(args, "bench.py needs an MI355X: the rasterizer has no CPU path", 3)
+    if torch.cuda.device_count() <= local_rank:
+        _error_record(args, f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)", 3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -249,13 +343,30 @@ def main():
             cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1, streams=args.count_streams)
         barrier()
         elapsed = time.perf_counter() - t0
+        from lightgaussian_amd import prune as _prune
+        # config C4's epilogue, the reference's own formulation (calculate_v_imp_score(v_pow=0.1) + prune_gaussians(0.66)): every
+        # rank holds the same reduced scores, hence the same mask; its digest goes into the JSON line
+        with torch.no_grad():
+            mask_all = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1))
         extra["significance_pass"] = {"views": args.steps * world, "seconds": round(elapsed, 4),
                                       "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item()),
-                                      "views_in_flight_per_rank": args.count_streams}
+                                      "views_in_flight_per_rank": args.count_streams, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                                      "prune_ratio": 0.66, "v_pow": 0.1, "pruned": int(mask_all.sum().item()), "mask_sha256": mask_digest(mask_all)}
+        if world > 1:
+            digests = [None] * world
+            dist.all_gather_object(digests, extra["significance_pass"]["mask_sha256"])
+            extra["significance_pass"]["mask_identical_on_all_ranks"] = len(set(digests)) == 1
+        if rank == 0 and world > 1 and not args.no_verify_1gpu:
+            # the same camera list on ONE rank (the plain single-process loop): the mask must not depend on the GPU count
+            with torch.no_grad():
+                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, local_only=True)
+                m1 = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, i1, 0.1))
+            extra["significance_pass"].update({"mask_equals_1gpu": bool(torch.equal(m1, mask_all)), "counts_equal_1gpu": bool(torch.equal(c1, cnt)),
+                                               "scores_bit_identical_1gpu": bool(torch.equal(i1, imp)), "mask_sha256_1gpu": mask_digest(m1)})
+            del c1, i1, m1
         if rank == 0:
-            # the epilogue of config C4 (untimed w.r.t. `value`): calculate_v_imp_score(v_pow=0.1) + prune mask at 66 %,
-            # device-resident radix selects (lg_prune_epilogue) next to the reference's torch formulation (2 sorts)
-            from lightgaussian_amd import prune as _prune
+            # the epilogue itself (untimed w.r.t. `value`): device-resident radix selects (prune_epilogue) next to the reference's
+            # torch formulation (2 full sorts + host indexing)
             def timed(fn, reps=5):
                 fn(); torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,10 +376,15 @@ def main():
                 b.record(); torch.cuda.synchronize()
                 return a.elapsed_time(b) / reps, out
             with torch.no_grad():
-                ms_hip, (v_hip, m_hip, _) = timed(lambda: _prune.prune_epilogue(pc, imp, 0.1, 0.66))
+                ms_sel, (v_sel, m_sel, _) = timed(lambda: _prune.prune_epilogue(pc, imp, 0.1, 0.66))
+                ms_fused, (v_f, m_f, _) = timed(lambda: _prune.prune_epilogue(pc, imp, 0.1, 0.66, fused_pow=True))
                 ms_torch, m_torch = timed(lambda: _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1)))
-            extra["significance_pass"]["epilogue"] = {"hip_ms": round(ms_hip, 4), "torch_ms": round(ms_torch, 4), "pruned": int(m_hip.sum().item()),
-                                                      "mask_disagreements_vs_torch": int((m_hip != m_torch).sum().item())}
+            extra["significance_pass"]["epilogue"] = {
+                "select_ms": round(ms_sel, 4), "fused_pow_ms": round(ms_fused, 4), "torch_sort_ms": round(ms_torch, 4),
+                "mask_hamming_vs_torch": int((m_sel != m_torch).sum().item()),
+                "fused_pow_mask_hamming_vs_torch": int((m_f != m_torch).sum().item()),
+                "note": "prune_epilogue (default): HIP radix selects around the reference's own torch.pow -> bit-identical mask; "
+                        "fused_pow=True evaluates powf in the kernel (1-ulp v_list, not the contract)"}
     elif args.views_in_flight > 1 and args.mode in ("fwdbwd", "fwd"):
         batch = make_batch_runner(args.views_in_flight)
         batch(0, args.warmup)

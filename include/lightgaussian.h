@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 3
+#define LG_ABI_VERSION 4
 
 enum {
     LG_OK = 0,
@@ -56,6 +56,9 @@ enum {
                               undefined); counts, scores and radii are unaffected.  Used by the sharded prune pass. */
     LG_FLAG_L1_ONLY = 32,  /* lg_loss_forward / lg_loss_backward only: mean |img - gt| without the SSIM work (out[1] = 0);
                               forward and backward must agree */
+    LG_FLAG_PAIR_SORT = 64,      /* cross-check switches (never needed in production): force the (tile<<32|depth, id) */
+    LG_FLAG_SORT_ALL_BITS = 128, /* pair format; sort every depth bit (no insertion completion in K5); K1 stages SH rows through */
+    LG_FLAG_K1_LDS = 256,        /* LDS instead of per-lane dwordx4 reads */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc
@@ -127,6 +130,24 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
                      void** binning_out, int64_t* num_rendered, void* stream);
 
 /*
+ * Capacity-bounded forward: the same render (plain when out_count/out_score are NULL, else + significance) WITHOUT the
+ * blocking device->host read of the instance count that lg_forward -- like the reference extension, whose Python side
+ * sizes its binning buffer from num_rendered (SURVEY 8b "one blocking D->H read of R per forward") -- performs.  The
+ * caller supplies the binning buffer for up to `max_rendered` instances (lg_binning_bytes(max_rendered, W, H); e.g.
+ * 1.25x the previous view's count) and an upper bound `max_depth` of the view-space depth (the camera's zfar), which fixes
+ * the key layout on the host.  Nothing is read back and every launch is stream-ordered, so a view's forward + backward can
+ * be issued from one host thread onto several streams, or captured into a hipGraph.
+ *   status: device uint32[4], written on `stream` = { abort flags, prefiltered violation, largest depth bit pattern,
+ *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth.  When status[0] != 0 the
+ *           view was abandoned on the device (every later kernel returns at once; outputs undefined, gradients of a
+ *           following lg_backward are zero) and the caller re-runs it through lg_forward -- the only host decision left.
+ * Backward: lg_backward(..., binning, num_rendered = max_rendered, ...) with scratch lg_backward_scratch_bytes(N, max_rendered).
+ */
+int lg_forward_bounded(const lg_view* view, const lg_gaussians* g, void* geom, void* img, void* binning, int64_t max_rendered,
+                       float max_depth, int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
+                       float* out_score, uint32_t* status, void* stream);
+
+/*
  * Backward  (replaces rasterize_gaussians_backward).  dL_dcolor [3,H,W] -> dense gradients, zero for
  * Gaussians that were not rasterised.  Output pointers may be NULL when the matching input was NULL.
  *   dL_dmeans2D [N,3] (NDC units, z = 0; consumed by scene/gaussian_model.py:784-788)
@@ -157,6 +178,35 @@ size_t lg_prune_scratch_bytes(int32_t N);
 int lg_prune_epilogue(int32_t N, const float* scaling, const float* imp_list, float v_pow, double prune_percent,
                       float* v_list, uint8_t* mask, float* thresholds, void* scratch, uint32_t flags, void* stream);
 
+/* One radix select: out_value[0] = the rank-th smallest (0-based) of values[0..N) -- exactly the element a sort puts at that
+ * index -- and, when mask != NULL, mask[i] = values[i] <= out_value (uint8).  The two order statistics of the epilogue
+ * above, usable around the reference's own torch.pow so that v_list and the mask stay bit-identical to prune.py:112-128 /
+ * scene/gaussian_model.py:776-782 (lightgaussian_amd.prune.prune_epilogue).  scratch: lg_prune_scratch_bytes(N). */
+int lg_select_mask(int32_t N, const float* values, int64_t rank, uint8_t* mask, float* out_value, void* scratch, void* stream);
+
+/* --- compaction after a prune --------------------------------------------------
+ * Replaces the tensor surgery of GaussianModel.prune_points / _prune_optimizer (scene/gaussian_model.py:564-600): every
+ * parameter, both Adam moments of every parameter and the three bookkeeping tensors are indexed with the keep-mask there
+ * (21 boolean-index kernels, each with a nonzero() + host sync).  lg_compact_plan: dest[i] = row of i among the kept rows
+ * (order preserved) or -1, *count = number kept (device int32; the ONE value the host reads to size the outputs).
+ * lg_compact_rows: moves the rows of up to 32 tensors in one launch; src/dst/row_bytes are HOST arrays of num_tensors device
+ * pointers / row sizes in bytes (multiples of 4); dst[t] holds >= *count rows.  Result == tensor[keep] bit for bit.
+ * keep: uint8 [N] (1 = keep).  scratch: lg_compact_scratch_bytes(N). */
+size_t lg_compact_scratch_bytes(int32_t N);
+int lg_compact_plan(int32_t N, const uint8_t* keep, int32_t* dest, int32_t* count, void* scratch, void* stream);
+int lg_compact_rows(int32_t N, const int32_t* dest, int32_t num_tensors, const void* const* src, void* const* dst,
+                    const int32_t* row_bytes, void* stream);
+
+/* --- VecTree nearest-code search (second half) ----------------------------------
+ * Replaces vectree/vq.py:262-266 (EuclideanCodebook.forward: dist = -torch.cdist(flatten, embed, p=2); embed_ind =
+ * dist.argmax(-1)) as driven by vectree/vectree.py:87-101: out_index[i] = argmin_c |x[i] - codebook[c]|^2, ties to the lowest
+ * c.  x [n,d], codebook [K,d] fp32 device (d <= 63: 27 / 48 in the reference, K = 8192), out_index [n] int32.
+ * f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32) on |c|^2 - 2 x.c with a fused per-point argmin; scratch:
+ * lg_vq_scratch_bytes(K, d) (the augmented codebook, rebuilt by every call). */
+size_t lg_vq_scratch_bytes(int32_t K, int32_t d);
+int lg_vq_nearest(int32_t n, int32_t d, int32_t K, const float* x, const float* codebook, int32_t* out_index, void* scratch,
+                  uint32_t flags, void* stream);
+
 /* out[j] = (((rows[0][j] + rows[1][j]) + rows[2][j]) + ...) over V rows of n floats (row pitch row_stride floats): the
  * sequential in-place float accumulation of per-view scores in prune.py:144-155, in view order, as one launch. */
 int lg_ordered_sum(int32_t V, int64_t n, const float* rows, int64_t row_stride, float* out, void* stream);
@@ -185,6 +235,12 @@ int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const flo
 int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const void* state,
                      const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
                      uint32_t flags, void* stream);
+
+/* diagnostics: K4 on its own -- stable ascending sort of bits [begin_bit, end_bit) of n < 2^30 64-bit keys (keys_in preserved);
+ * temp: lg_debug_sort_temp_bytes(n) device bytes */
+size_t lg_debug_sort_temp_bytes(int64_t n);
+int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, int32_t begin_bit, int32_t end_bit, void* temp,
+                       void* stream);
 
 /* diagnostics: the packed wave reduction used by the backward blend, on one wave: in [64][9] -> out [9] */
 int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream);

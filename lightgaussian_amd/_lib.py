@@ -20,12 +20,15 @@ LG_ERR_PREFILTERED = -4
 
 WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
 FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_L1_ONLY = 1, 2, 4, 8, 16, 32
+FLAG_PAIR_SORT, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
            "lg_profile_read", "lg_profile_reset", "lg_last_stats", "lg_debug_reduce9", "lg_loss_state_bytes",
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
-           "lg_knn3_mean_dist2", "lg_ordered_sum"]
+           "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
+           "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
+           "lg_debug_sort_keys"]
 
 
 class lg_view(C.Structure):
@@ -100,6 +103,21 @@ def load():
     lib.lg_knn3_mean_dist2.argtypes = [C.c_int32, vp, vp, vp, C.c_uint32, vp]
     lib.lg_ordered_sum.restype = C.c_int
     lib.lg_ordered_sum.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp]
+    lib.lg_forward_bounded.restype = C.c_int
+    lib.lg_forward_bounded.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp]
+    lib.lg_select_mask.restype = C.c_int
+    lib.lg_select_mask.argtypes = [C.c_int32, vp, C.c_int64, vp, vp, vp, vp]
+    lib.lg_compact_scratch_bytes.restype = C.c_size_t; lib.lg_compact_scratch_bytes.argtypes = [C.c_int32]
+    lib.lg_compact_plan.restype = C.c_int
+    lib.lg_compact_plan.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
+    lib.lg_compact_rows.restype = C.c_int
+    lib.lg_compact_rows.argtypes = [C.c_int32, vp, C.c_int32, P(vp), P(vp), P(C.c_int32), vp]
+    lib.lg_vq_scratch_bytes.restype = C.c_size_t; lib.lg_vq_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.lg_vq_nearest.restype = C.c_int
+    lib.lg_vq_nearest.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.lg_debug_sort_temp_bytes.restype = C.c_size_t; lib.lg_debug_sort_temp_bytes.argtypes = [C.c_int64]
+    lib.lg_debug_sort_keys.restype = C.c_int
+    lib.lg_debug_sort_keys.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []

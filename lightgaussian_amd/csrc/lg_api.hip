@@ -8,6 +8,8 @@
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
+//   lg_compact.h     lg_compact_plan / lg_compact_rows: one scan + one launch compacting all Gaussian tensors after a prune
+//   lg_vq.h          lg_vq_nearest: nearest-code search of the VecTree quantiser on f32 MFMA (32x32x2), fused row argmin
 //   lg_blend.h       K6 lg_blend_fwd<COUNT,FSCORE,EXACT>, lg_score_kernel, K7 lg_blend_bwd<EXACT>   (per tile, VALU-bound)
 //
 // Pipeline of one view:
@@ -27,6 +29,8 @@
 #include "lg_loss.h"
 #include "lg_prune.h"
 #include "lg_knn.h"
+#include "lg_compact.h"
+#include "lg_vq.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -89,13 +93,41 @@ struct PinnedSlot {
         }                                                                                    \
     } while (0)
 
+// Layout of the sort key of one view: tile | (depth bits - bias) | Gaussian id.  Exact forward: from the read-back depth
+// maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
+#define LG_MIN_DEPTH_BITS 18
+struct KeyPlan { bool packed; int tile_bits, gid_bits, depth_bits, drop; uint32_t gid_mask; };
+static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t flags)
+{
+    KeyPlan k;
+    k.tile_bits = bits_for((uint32_t)ntiles);
+    k.gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
+    const uint32_t dspan = dmax_bits > LG_DEPTH_BIAS ? dmax_bits - LG_DEPTH_BIAS : 0u;
+    k.depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
+    k.packed = (k.tile_bits + k.depth_bits + k.gid_bits <= 64) && !(flags & LG_FLAG_PAIR_SORT);
+    // The radix sort works in 8-bit passes.  The lowest `drop` depth bits are left to lg_tile_ranges (runs of equal sorted
+    // bits are finished there by insertion) whenever that saves whole passes and at least LG_MIN_DEPTH_BITS depth bits
+    // (sign-free float pattern: exponent + >= 13 mantissa bits at scene depths) stay in the sort: 39 -> 32 sorted bits at
+    // C3 (exact forward, 26 depth bits), 40 -> 32 in the bounded forward (27 bits for a zfar of 100).
+    k.drop = 0;
+    if (k.packed && !(flags & LG_FLAG_SORT_ALL_BITS)) {
+        const int sorted = k.tile_bits + k.depth_bits;
+        for (int d = sorted % 8; d <= k.depth_bits - LG_MIN_DEPTH_BITS; d += 8) k.drop = d;   // the largest admissible
+    }
+    k.gid_mask = k.gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << k.gid_bits) - 1u);
+    return k;
+}
+
+// Arguments of the capacity-bounded forward (lg_forward_bounded); NULL = exact forward with its one read-back.
+struct Bounded { void* binning; int64_t capacity; float max_depth; uint32_t* status; };
+
 static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, void* img_p, lg_alloc_fn alloc, void* alloc_user,
-                        int weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count, float* out_score,
-                        void** binning_out, int64_t* num_rendered, void* stream_p)
+                        const Bounded* bounded, int weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
+                        float* out_score, void** binning_out, int64_t* num_rendered, void* stream_p)
 {
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
-    if (!geom_p || !img_p || !out_color || (!out_radii && g->N > 0) || !alloc) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    if (!geom_p || !img_p || !out_color || (!out_radii && g->N > 0) || (!alloc && !bounded)) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
     const bool count = out_count != nullptr;
     if (count && !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count needs score");
     if (count && (weight_policy < 0 || weight_policy > 3)) return fail(LG_ERR_INVALID_ARGUMENT, "bad weight policy");
@@ -104,21 +136,39 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const int N = g->N, W = v->image_width, H = v->image_height;
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE, ntiles = gx * gy;
     const int ntiles_pad = (ntiles + LG_TILE_GRID_ALIGN - 1) / LG_TILE_GRID_ALIGN * LG_TILE_GRID_ALIGN; // grid of the per-tile kernels
+    const int nblk = (N + LG_PP - 1) / LG_PP;
     GeomView geo = carve_geom(geom_p, N);
     ImgView img = carve_img(img_p, W, H);
     if (binning_out) *binning_out = nullptr;
     if (num_rendered) *num_rendered = 0;
-    uint32_t h_counters[3] = {0, 0, 0}, h_R = 0;
+
+    KeyPlan kp{};
+    BinView bin{};
+    int64_t cap = 0;          // instances the binning buffer holds: R itself (exact) or the caller's capacity (bounded)
+    if (bounded) {
+        if (!bounded->binning || bounded->capacity <= 0 || bounded->capacity >= (1ll << 30) || !(bounded->max_depth > 0.2f))
+            return fail(LG_ERR_INVALID_ARGUMENT, "lg_forward_bounded: binning buffer, 0 < max_rendered < 2^30 and max_depth > 0.2 required");
+        kp = make_key_plan(ntiles, N, __builtin_bit_cast(uint32_t, bounded->max_depth), v->flags);
+        if (!kp.packed) return fail(LG_ERR_INVALID_ARGUMENT, "lg_forward_bounded: tile | depth | id exceed 64 key bits; use lg_forward");
+        cap = bounded->capacity;
+        bin = carve_bin(bounded->binning, cap, W, H, true);
+        if (binning_out) *binning_out = bounded->binning;
+        if (num_rendered) *num_rendered = cap;
+        if (N == 0) {
+            HIP_TRY(hipMemsetAsync(geo.counters, 0, 16, stream));
+            HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
+        }
+    }
     if (N > 0) {
         {
             ProfScope ps(prof, "preprocess", stream);
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
-    lg_preprocess<RAWP, DIR><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,      \
+    lg_preprocess<RAWP, DIR><<<nblk, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score)
             // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
-            const bool direct = getenv("LG_K1_LDS") == nullptr;
+            const bool direct = !(v->flags & LG_FLAG_K1_LDS);
             const bool raw = v->flags & LG_FLAG_RAW_PARAMS;
             if (raw && direct) LAUNCH_PP(true, true);
             else if (raw) LAUNCH_PP(true, false);
@@ -128,79 +178,87 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_preprocess");
         {
+            // K2: one workgroup scans the per-K1-workgroup instance counts and reduces the depth maxima (replaces a
+            // device-wide scan of N words + a separate reduction kernel)
             ProfScope ps(prof, "scan", stream);
-            size_t tb = geo.scan_temp_bytes;
-            HIP_TRY(hipcub::DeviceScan::InclusiveSum(geo.scan_temp, tb, geo.touched, geo.offsets, N, stream));
+            lg_scan_blocks<<<1, 1024, 0, stream>>>(nblk, geo.blk_sum, geo.blk_dmax, geo.blk_off, bounded ? (uint32_t)cap : 0xFFFFFFFFu,
+                                                   bounded ? kp.depth_bits : 32, geo.counters);
         }
-        // The forward has ONE blocking read-back: the instance count R (it sizes the binning buffers), with the depth
-        // maximum and the prefiltered flag riding along: lg_reduce_dmax gathers them into counters[0..3] and a single
-        // 16-byte copy into pinned host memory fetches them.  (Two pageable copies, the first version, cost two host round
-        // trips: ~100 us of idle GPU per view in the kernel trace, now ~70.  Polling a host-mapped mailbox written by the
-        // kernel instead of hipStreamSynchronize was measured as well: no difference, so the plain form stays.)
-        lg_reduce_dmax<<<1, 1024, 0, stream>>>((N + LG_PP - 1) / LG_PP, geo.blk_dmax, geo.offsets + (N - 1), geo.counters);
-        KCHECK("lg_reduce_dmax");
-        PinnedSlot slot;                                      // process-wide pool: host threads come and go (views in flight)
-        if (!slot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the read-back slot failed");
-        HIP_TRY(hipMemcpyAsync(slot.p, geo.counters, 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        h_counters[0] = slot.p[0]; h_counters[1] = slot.p[1]; h_counters[2] = slot.p[2];
-        h_R = slot.p[3];
-        if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        KCHECK("lg_scan_blocks");
     }
-    const int64_t R = h_R;
-    if (R > 0x7FFFFFFFll) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^31-1 tile instances in one view");
-    g_stats.num_rendered = R;
+    int64_t R = cap;
+    if (!bounded) {
+        uint32_t h_counters[4] = {0, 0, 0, 0};
+        if (N > 0) {
+            // The exact forward has ONE blocking read-back: the instance count R (it sizes the binning buffer), with the
+            // depth maximum and the prefiltered flag riding along in one 16-byte copy into pinned host memory.
+            // lg_forward_bounded has none.
+            PinnedSlot slot;                                      // process-wide pool: host threads come and go (views in flight)
+            if (!slot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the read-back slot failed");
+            HIP_TRY(hipMemcpyAsync(slot.p, geo.counters, 16, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int k = 0; k < 4; k++) h_counters[k] = slot.p[k];
+            if (v->prefiltered && h_counters[1]) return fail(LG_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+            if (h_counters[0] & 1u) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^32-1 tile instances in one view");
+        }
+        R = h_counters[3];
+        if (R >= (1ll << 30)) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^30-1 tile instances in one view");
+        kp = make_key_plan(ntiles, N, h_counters[2], v->flags);
+        void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, kp.packed).total);
+        if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
+        if (binning_out) *binning_out = bin_p;
+        bin = carve_bin(bin_p, R, W, H, kp.packed);
+        cap = R;
+        if (num_rendered) *num_rendered = R;
+        if (R == 0) HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
+    } else if (bounded->status) {
+        HIP_TRY(hipMemcpyAsync(bounded->status, geo.counters, 16, hipMemcpyDeviceToDevice, stream));
+    }
+    g_stats.num_rendered = bounded ? -1 : R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
-    if (num_rendered) *num_rendered = R;
 
-    // key format: packed single-u64 keys when tile | depth | id fit 64 bits (they do for every BASELINE config)
-    const int tile_bits = bits_for((uint32_t)ntiles), gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
-    const uint32_t dspan = h_counters[2] > LG_DEPTH_BIAS ? h_counters[2] - LG_DEPTH_BIAS : 0u;
-    const int depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
-    const bool packed = (tile_bits + depth_bits + gid_bits <= 64) && (getenv("LG_FORCE_PAIR_SORT") == nullptr);
-    // the radix sort works in 8-bit passes: when the tile + depth field is a few bits over a multiple of 8, those lowest
-    // depth bits are left to lg_tile_ranges (runs of equal sorted bits are finished by insertion) and a whole pass is saved
-    int drop = (tile_bits + depth_bits) % 8;
-    if (!packed || depth_bits - drop < 12 || getenv("LG_SORT_ALL_BITS") != nullptr) drop = 0;
-
-    void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, packed).total);
-    if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
-    if (binning_out) *binning_out = bin_p;
-    BinView bin = carve_bin(bin_p, R, W, H, packed);
-    if (R == 0) HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
-    const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
-    if (R > 0) {
+    const int sort_begin = kp.gid_bits + kp.drop, sort_end = kp.gid_bits + kp.depth_bits + kp.tile_bits;
+    if (cap > 0 && N > 0) {
+        const LgSortLayout SL = lg_sort_layout((size_t)cap);
+        uint32_t* hist = nullptr;
+        if (kp.packed) {
+            // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass
+            HIP_TRY(hipMemsetAsync(bin.sort_temp, 0, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
+            hist = (uint32_t*)((char*)bin.sort_temp + SL.hist_off);
+        }
         {
             ProfScope ps(prof, "duplicate", stream);
-            if (packed)
-                lg_duplicate<true><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, depth_bits, gid_bits, geo.touched, geo.offsets, geo.tinfo,
-                                                                        bin.keys_in, nullptr, ntiles, bin.ranges);
+            const int dgrid = std::max(1, std::min((nblk + 3) / 4, 1024));
+            if (kp.packed)
+                lg_duplicate<true><<<dgrid, 256, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
+                                                              geo.blk_off, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);
             else
-                lg_duplicate<false><<<(N + 255) / 256, 256, 0, stream>>>(N, gx, 0, 0, geo.touched, geo.offsets, geo.tinfo, bin.keys_in,
-                                                                         bin.vals_in, ntiles, bin.ranges);
+                lg_duplicate<false><<<dgrid, 256, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.counters, geo.offsets,
+                                                               geo.tinfo, bin.keys_in, bin.vals_in, ntiles, bin.ranges, nullptr);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
-            if (packed)
-                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (unsigned)R, (unsigned)(gid_bits + drop),
-                                     (unsigned)(gid_bits + depth_bits + tile_bits), stream));
+            if (kp.packed)
+                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (uint32_t)cap, sort_begin, sort_end, geo.counters, true, stream));
             else
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_tmp, bin.vals_in, bin.vals_out, (int)R, 0,
-                                                           32 + tile_bits, stream));
+                                                           32 + kp.tile_bits, stream));
         }
+        KCHECK("lg_sort_keys");
         {
             ProfScope ps(prof, "tile_ranges", stream);
-            if (packed)
-                lg_tile_ranges<true><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, depth_bits + gid_bits, gid_bits, drop,
-                                                                                      bin.entries, nullptr, bin.entries, bin.keys_in, bin.ranges);
+            const uint32_t rgrid = (uint32_t)((cap + 255) / 256);
+            if (kp.packed)
+                lg_tile_ranges<true><<<rgrid, 256, 0, stream>>>(geo.counters, kp.depth_bits + kp.gid_bits, kp.gid_bits, kp.drop,
+                                                                bin.entries, nullptr, bin.entries, bin.keys_in, bin.ranges);
             else
-                lg_tile_ranges<false><<<(uint32_t)((R + 255) / 256), 256, 0, stream>>>((uint32_t)R, 32, 0, 0, bin.keys_tmp, bin.vals_out,
-                                                                                       bin.entries, nullptr, bin.ranges);
+                lg_tile_ranges<false><<<rgrid, 256, 0, stream>>>(geo.counters, 32, 0, 0, bin.keys_tmp, bin.vals_out, bin.entries, nullptr, bin.ranges);
         }
         KCHECK("lg_tile_ranges");
     }
+    const uint32_t gid_mask = kp.gid_mask;
     // (count / score accumulators of the count variant were cleared by lg_preprocess)
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
@@ -231,7 +289,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 extern "C" int lg_forward(const lg_view* view, const lg_gaussians* g, void* geom, void* img, lg_alloc_fn alloc, void* alloc_user,
                           float* out_color, int32_t* out_radii, void** binning_out, int64_t* num_rendered, void* stream)
 {
-    return forward_impl(view, g, geom, img, alloc, alloc_user, LG_WEIGHT_OPACITY, out_color, out_radii, nullptr, nullptr, binning_out,
+    return forward_impl(view, g, geom, img, alloc, alloc_user, nullptr, LG_WEIGHT_OPACITY, out_color, out_radii, nullptr, nullptr, binning_out,
                         num_rendered, stream);
 }
 
@@ -240,8 +298,17 @@ extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void
                                 void** binning_out, int64_t* num_rendered, void* stream)
 {
     if (g && g->N > 0 && (!out_count || !out_score)) return fail(LG_ERR_INVALID_ARGUMENT, "count/score outputs required");
-    return forward_impl(view, g, geom, img, alloc, alloc_user, weight_policy, out_color, out_radii, out_count, out_score, binning_out,
+    return forward_impl(view, g, geom, img, alloc, alloc_user, nullptr, weight_policy, out_color, out_radii, out_count, out_score, binning_out,
                         num_rendered, stream);
+}
+
+extern "C" int lg_forward_bounded(const lg_view* view, const lg_gaussians* g, void* geom, void* img, void* binning, int64_t max_rendered,
+                                  float max_depth, int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
+                                  float* out_score, uint32_t* status, void* stream)
+{
+    if (g && g->N > 0 && ((out_count == nullptr) != (out_score == nullptr))) return fail(LG_ERR_INVALID_ARGUMENT, "count and score go together");
+    const Bounded b = { binning, max_rendered, max_depth, status };
+    return forward_impl(view, g, geom, img, nullptr, nullptr, &b, weight_policy, out_color, out_radii, out_count, out_score, nullptr, nullptr, stream);
 }
 
 extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
@@ -251,6 +318,7 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
 {
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
+    if (g->N == 0) return LG_OK;   // empty model: torch hands over NULL pointers for empty tensors, and there is nothing to write
     if (g->shs_rest && !dL_dshs_rest) return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for shs_rest");
     if (!radii || !geom_p || !bin_p || !img_p || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacity || !scratch)
         return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
@@ -292,8 +360,8 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
 #define LAUNCH_PPB(RAWP)                                                                                                             \
     lg_preprocess_bwd<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(                                                           \
         N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
-        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.aux, geo.touched,  \
-        geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec, geo.aux,   \
+        geo.counters, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
         if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
 #undef LAUNCH_PPB
@@ -351,6 +419,27 @@ extern "C" int lg_prune_epilogue(int32_t N, const float* scaling, const float* i
     return LG_OK;
 }
 
+// rank-th smallest element of values[0..N) by one radix select (four 8-bit histogram passes; exact: the element a sort puts
+// at that index) and, when mask != NULL, mask[i] = values[i] <= that element.  The two halves of the prune epilogue around the
+// reference's own torch.pow (prune.prune_epilogue): no sort, no host read-back.
+extern "C" int lg_select_mask(int32_t N, const float* values, int64_t rank, uint8_t* mask, float* out_value, void* scratch, void* stream_p)
+{
+    if (N <= 0 || rank < 0 || rank >= N) return fail(LG_ERR_INVALID_ARGUMENT, "lg_select_mask needs N >= 1 and 0 <= rank < N");
+    if (!values || !out_value || !scratch) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = false;
+    LgSelect* st = (LgSelect*)scratch;
+    const int blocks = (int)std::min<int64_t>(((int64_t)N + 255) / 256, 2048);
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(LgSelect), stream));
+    for (int p = 0; p < 4; p++) {
+        lg_select_pass<1><<<blocks, 256, 0, stream>>>(N, p, (uint32_t)rank, values, st);
+        KCHECK("lg_select_pass");
+    }
+    lg_select_finish_kernel<<<mask ? blocks : 1, 256, 0, stream>>>(N, (uint32_t)rank, values, st, mask, out_value);
+    KCHECK("lg_select_finish_kernel");
+    return LG_OK;
+}
+
 extern "C" int lg_ordered_sum(int32_t V, int64_t n, const float* rows, int64_t row_stride, float* out, void* stream_p)
 {
     if (V <= 0 || n < 0 || row_stride < n) return fail(LG_ERR_INVALID_ARGUMENT, "bad shape");
@@ -360,6 +449,94 @@ extern "C" int lg_ordered_sum(int32_t V, int64_t n, const float* rows, int64_t r
     lg_ordered_sum_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(V, (size_t)n, rows, (size_t)row_stride, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_ordered_sum_kernel launch", e);
+    return LG_OK;
+}
+
+// ---- compaction of the Gaussian tensors after a prune (scene/gaussian_model.py:564-600) ----
+extern "C" size_t lg_compact_scratch_bytes(int32_t N)
+{
+    const size_t nb = ((size_t)(N > 0 ? N : 1) + LG_COMPACT_ROWS - 1) / LG_COMPACT_ROWS;
+    return 2 * align_up(nb * 4);
+}
+
+extern "C" int lg_compact_plan(int32_t N, const uint8_t* keep, int32_t* dest, int32_t* count, void* scratch, void* stream_p)
+{
+    if (N < 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad row count");
+    if (!count || (N > 0 && (!keep || !dest || !scratch))) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = false;
+    if (N == 0) { HIP_TRY(hipMemsetAsync(count, 0, 4, stream)); return LG_OK; }
+    const int nb = (N + LG_COMPACT_ROWS - 1) / LG_COMPACT_ROWS;
+    uint32_t* blk_sum = (uint32_t*)scratch;
+    uint32_t* blk_off = (uint32_t*)((char*)scratch + align_up((size_t)nb * 4));
+    lg_compact_count<<<nb, 256, 0, stream>>>(N, keep, blk_sum);
+    KCHECK("lg_compact_count");
+    lg_scan_words<<<1, 1024, 0, stream>>>(nb, blk_sum, blk_off, count);
+    KCHECK("lg_scan_words");
+    lg_compact_dest<<<nb, 256, 0, stream>>>(N, keep, blk_off, dest);
+    KCHECK("lg_compact_dest");
+    return LG_OK;
+}
+
+extern "C" int lg_compact_rows(int32_t N, const int32_t* dest, int32_t num_tensors, const void* const* src, void* const* dst,
+                               const int32_t* row_bytes, void* stream_p)
+{
+    if (N < 0 || num_tensors < 0 || num_tensors > LG_COMPACT_MAX_TENSORS) return fail(LG_ERR_INVALID_ARGUMENT, "bad tensor count (max 32 per call)");
+    if (N == 0 || num_tensors == 0) return LG_OK;
+    if (!dest || !src || !dst || !row_bytes) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = false;
+    LgCompactArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t widest = 1;
+    for (int t = 0; t < num_tensors; t++) {
+        if (row_bytes[t] <= 0 || (row_bytes[t] & 3) || !src[t] || !dst[t] || ((uintptr_t)src[t] & 3) || ((uintptr_t)dst[t] & 3))
+            return fail(LG_ERR_INVALID_ARGUMENT, "lg_compact_rows: rows must be non-empty multiples of 4 bytes, 4-byte aligned");
+        a.src[t] = (const uint32_t*)src[t]; a.dst[t] = (uint32_t*)dst[t]; a.words[t] = (uint32_t)(row_bytes[t] / 4);
+        widest = std::max<size_t>(widest, a.words[t]);
+    }
+    const size_t blocks = std::min<size_t>(((size_t)N * widest + 1023) / 1024, 8192);
+    lg_compact_move<<<dim3((unsigned)std::max<size_t>(blocks, 1), (unsigned)num_tensors), 256, 0, stream>>>(N, dest, a);
+    KCHECK("lg_compact_move");
+    return LG_OK;
+}
+
+// ---- VecTree nearest-code search (vectree/vq.py:262-266) ----
+extern "C" size_t lg_vq_scratch_bytes(int32_t K, int32_t d)
+{
+    const int dk2 = lg_vq_dk2(d);
+    if (K <= 0 || d <= 0 || dk2 == 0) return 0;
+    return align_up((size_t)lg_vq_kpad(K) * 2 * dk2 * sizeof(float));
+}
+
+extern "C" int lg_vq_nearest(int32_t n, int32_t d, int32_t K, const float* x, const float* codebook, int32_t* out_index, void* scratch,
+                             uint32_t flags, void* stream_p)
+{
+    const int dk2 = lg_vq_dk2(d);
+    if (n < 0 || K <= 0 || d <= 0 || dk2 == 0) return fail(LG_ERR_INVALID_ARGUMENT, "lg_vq_nearest: need n >= 0, K >= 1, 1 <= d <= 63");
+    if (n == 0) return LG_OK;
+    if (!x || !codebook || !out_index || !scratch) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
+    const int Kpad = lg_vq_kpad(K), dk = 2 * dk2;
+    float* cbA = (float*)scratch;
+    ProfScope ps(prof, "vq_nearest", stream);
+    lg_vq_prepare<<<(Kpad + 255) / 256, 256, 0, stream>>>(K, Kpad, d, dk, codebook, cbA);
+    KCHECK("lg_vq_prepare");
+    const unsigned grid = (unsigned)((n + 127) / 128);
+#define LAUNCH_VQ(D2) lg_vq_nearest_kernel<D2><<<grid, 256, 0, stream>>>(n, d, Kpad, x, cbA, out_index)
+    switch (dk2) {
+        case 2: LAUNCH_VQ(2); break;
+        case 4: LAUNCH_VQ(4); break;
+        case 7: LAUNCH_VQ(7); break;
+        case 8: LAUNCH_VQ(8); break;
+        case 14: LAUNCH_VQ(14); break;
+        case 16: LAUNCH_VQ(16); break;
+        case 25: LAUNCH_VQ(25); break;
+        default: LAUNCH_VQ(32); break;
+    }
+#undef LAUNCH_VQ
+    KCHECK("lg_vq_nearest_kernel");
     return LG_OK;
 }
 
@@ -460,6 +637,19 @@ extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* im
                                               (float)(1.0 / ((double)C * H * W)), dL_dimg);
         KCHECK("lg_loss_bwd");
     }
+    return LG_OK;
+}
+
+// diagnostics: the K4 radix sort on its own (stand-alone histogram pass + onesweep passes)
+extern "C" size_t lg_debug_sort_temp_bytes(int64_t n) { return n < 0 ? 0 : lg_sort_layout((size_t)n).total; }
+extern "C" int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, int32_t begin_bit, int32_t end_bit, void* temp,
+                                  void* stream_p)
+{
+    if (n < 0 || n >= (1ll << 30) || begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit) return fail(LG_ERR_INVALID_ARGUMENT, "bad sort arguments");
+    if (n == 0) return LG_OK;
+    if (!keys_in || !keys_out || !temp) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    size_t tb = lg_sort_layout((size_t)n).total;
+    HIP_TRY(lg_sort_keys(temp, tb, keys_in, keys_out, (uint32_t)n, begin_bit, end_bit, nullptr, false, (hipStream_t)stream_p));
     return LG_OK;
 }
 

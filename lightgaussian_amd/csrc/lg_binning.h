@@ -6,70 +6,171 @@
 #include "lg_wave.h"
 
 // ------------------------------------------------------------------------------------------------
-// Gathers what the host reads back after the scan into counters[0..3] (every word written: no memset of the counters):
-// [1] = any prefiltered violation (bit 31 of the per-workgroup words), [2] = max over the per-workgroup depth maxima,
-// [3] = instance count of the view (last element of the inclusive scan).
+// K2: exclusive scan of the per-workgroup instance counts of K1 (one word per 64 Gaussians) by ONE workgroup, fused with
+// the reduction of the per-workgroup depth maxima / prefiltered flags.  counters[0..3] (every word written: no memset):
+//   [0] abort flags of the view: bit 0 = more instances than `capacity`, bit 1 = a depth beyond the `depth_bits` the keys
+//       were laid out for (both can only fire in the capacity-bounded forward, whose host side knows neither number);
+//       every later kernel of the view returns at once when [0] != 0
+//   [1] any prefiltered violation (bit 31 of the per-workgroup words)   [2] largest depth bit pattern   [3] R
+// Loads are issued 8 chunks ahead: a single workgroup walking 47k words pays one memory latency per dependent step.
+#define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
+#define LG_SCAN_AHEAD 8
+
 __global__ void __launch_bounds__(1024)
-lg_reduce_dmax(int nblk, const uint32_t* __restrict__ blk_dmax, const uint32_t* __restrict__ last_offset, uint32_t* __restrict__ counters)
+lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ blk_off,
+               uint32_t capacity, int depth_bits, uint32_t* __restrict__ counters)
 {
+    __shared__ uint32_t wsum[LG_SCAN_AHEAD][16];
     __shared__ uint32_t wmax[16], wflag[16];
-    uint32_t m = 0, f = 0;
-    // this single block sits on the critical path of the forward's read-back: 16-byte loads (the array is 256-byte aligned)
-    const int nvec = nblk >> 2;
-    for (int i = threadIdx.x; i < nvec; i += 1024) {
-        const uint4 v = reinterpret_cast<const uint4*>(blk_dmax)[i];
-        m = max(max(m, v.x & 0x7FFFFFFFu), max(v.y & 0x7FFFFFFFu, max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu)));
-        f |= (v.x | v.y | v.z | v.w) >> 31;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t m = 0, f = 0, carry = 0;
+    uint32_t overflow = 0;                        // the running sum passed 2^32 (an instance count no buffer could hold)
+    for (int base = 0; base < nblk; base += 1024 * LG_SCAN_AHEAD) {
+        uint32_t v[LG_SCAN_AHEAD], inc[LG_SCAN_AHEAD];
+#pragma unroll
+        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
+            const int i = base + c * 1024 + (int)tid;
+            v[c] = i < nblk ? blk_sum[i] : 0u;
+            const uint32_t d = i < nblk ? blk_dmax[i] : 0u;
+            m = max(m, d & 0x7FFFFFFFu);
+            f |= d >> 31;
+        }
+#pragma unroll
+        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
+            uint32_t x = v[c];
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const uint32_t o = __shfl_up(x, s, 64);
+                if ((int)lane >= s) x += o;
+            }
+            inc[c] = x;
+            if (lane == 63u) wsum[c][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
+            uint32_t woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const uint32_t t = wsum[c][w];
+                woff += (w < (int)wave) ? t : 0u;
+                total += t;
+            }
+            const int i = base + c * 1024 + (int)tid;
+            if (i < nblk) blk_off[i] = carry + woff + inc[c] - v[c];
+            const uint32_t nc = carry + total;
+            overflow |= (nc < carry) ? 1u : 0u;
+            carry = nc;
+        }
+        __syncthreads();
     }
-    for (int i = (nvec << 2) + threadIdx.x; i < nblk; i += 1024) { const uint32_t v = blk_dmax[i]; m = max(m, v & 0x7FFFFFFFu); f |= v >> 31; }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
-    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wflag[threadIdx.x >> 6] = f; }
+    if (lane == 0u) { wmax[wave] = m; wflag[wave] = f; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         for (int w = 1; w < 16; w++) { m = max(m, wmax[w]); f |= wflag[w]; }
-        counters[0] = 0;
+        const uint32_t dspan = m > LG_DEPTH_BIAS ? m - LG_DEPTH_BIAS : 0u;
+        uint32_t abort = (carry > capacity || overflow) ? 1u : 0u;
+        if (depth_bits < 32 && (dspan >> depth_bits) != 0u) abort |= 2u;
+        counters[0] = abort;
         counters[1] = f;
         counters[2] = m;
-        counters[3] = last_offset[0];
+        counters[3] = overflow ? 0xFFFFFFFFu : carry;
     }
 }
 
 // K3: duplicate with keys
 // Key formats.  PACKED: tile | (depth bits - bias) | Gaussian id in one u64, sorted keys-only on the tile+depth
-// bits: the stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free
-// (5 passes x 16 B instead of 6 x 24 B).  PAIRS (fallback when the fields do not fit 64 bits): tile<<32 | depth
-// with the Gaussian id as value.
-#define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
-
+// bits: the stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free.
+// PAIRS (fallback when the fields do not fit 64 bits): tile<<32 | depth with the Gaussian id as value.
+//
+// Wave-cooperative expansion: a wave takes the 64 Gaussians of one K1 workgroup, scans their instance counts, and then
+// LANE l WRITES INSTANCE p = 64 c + l of the wave (c = 0, 1, ...), finding its Gaussian by a 6-step binary search over
+// the 64 exclusive offsets in LDS -- consecutive lanes write consecutive 8-byte keys (one 512-byte store per wave
+// instruction; the thread-per-Gaussian version wrote one scattered 8-byte store per lane: WRITE_SIZE 2.3x the key
+// bytes).  The keys are in registers here, so the digit histograms of all radix passes are accumulated on the spot (LDS
+// atomics, flushed once per workgroup): the sort needs no counting pass over the keys.  Persistent grid: a workgroup's 4
+// waves walk K1 workgroups b = 4 blockIdx + wave, + 4 gridDim, ...
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_duplicate(int N, int gx, int depth_bits, int gid_bits, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets,
-             uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int ntiles, uint2* __restrict__ ranges)
+lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
+             const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ counters,
+             uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+             int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t lh[PACKED ? LG_SORT_MAX_PASSES * 256 : 1];
+    __shared__ uint32_t s_exc[4][64], s_xy[4][64], s_w[4][64], s_hi[4][64], s_lo[4][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // empty tiles keep {0, 0}: cleared here (this kernel runs before the sort) instead of by a memset
-    for (int t = i; t < ntiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
-    if (i >= N) return;
-    const uint32_t t = touched[i];
-    if (t == 0) return;
-    uint32_t off = offsets[i] - t;
-    const uint4 r = tinfo[i];
-    const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
-    tinfo[i].w = off; // slot base of this Gaussian's instances (lg_slot_of: row address in the backward)
+    for (int t = blockIdx.x * 256 + (int)tid; t < ntiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
+    const int passes = PACKED ? (sort_end - sort_begin + 7) / 8 : 0;
     if (PACKED) {
-        const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
-        const int sh = depth_bits + gid_bits;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) keys[off++] = ((uint64_t)(uint32_t)(y * gx + x) << sh) | low;
-    } else {
-        const uint64_t d = (uint64_t)r.z;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | d;
-                vals[off] = (uint32_t)i;
-                off++;
+        for (int i = (int)tid; i < passes * 256; i += 256) lh[i] = 0;
+        __syncthreads();
+    }
+    if (counters[0] != 0u) return;                 // view aborted by lg_scan_blocks (capacity-bounded forward)
+    const int sh = depth_bits + gid_bits;
+    for (int b = blockIdx.x * 4 + (int)wave; b < nblk; b += gridDim.x * 4) {
+        const int i = b * 64 + (int)lane;
+        const uint32_t t = i < N ? touched[i] : 0u;
+        uint32_t inc = t;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(inc, s, 64);
+            if ((int)lane >= s) inc += o;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        const uint32_t base = blk_off[b];
+        if (i < N) offsets[i] = base + inc;        // inclusive scan, as K9 expects (slot base = offsets - touched)
+        if (total == 0u) continue;                 // wave-uniform
+        const uint32_t exc = inc - t;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (t) {
+            r = tinfo[i];
+            tinfo[i].w = base + exc;               // slot base of this Gaussian's instances (lg_slot_of: row address in the backward)
+        }
+        s_exc[wave][lane] = exc;
+        s_xy[wave][lane] = r.x;
+        s_w[wave][lane] = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
+        if (PACKED) {
+            const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
+            s_lo[wave][lane] = (uint32_t)low;
+            s_hi[wave][lane] = (uint32_t)(low >> 32);
+        } else {
+            s_lo[wave][lane] = r.z;                // depth bits
+            s_hi[wave][lane] = (uint32_t)i;        // value = Gaussian id
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t p = lane; p < total; p += 64u) {
+            uint32_t j = 0;                        // largest j with exc[j] <= p: the Gaussian that owns instance p
+#pragma unroll
+            for (uint32_t step = 32; step > 0; step >>= 1)
+                if (s_exc[wave][j + step] <= p) j += step;
+            const uint32_t k = p - s_exc[wave][j], w = s_w[wave][j], xy = s_xy[wave][j];
+            const uint32_t ky = k / w, kx = k - ky * w;
+            const uint32_t tile = ((xy >> 16) + ky) * (uint32_t)gx + (xy & 0xFFFFu) + kx;
+            const uint64_t pos = (uint64_t)base + p;
+            if (PACKED) {
+                const uint64_t key = ((uint64_t)tile << sh) | ((uint64_t)s_hi[wave][j] << 32) | s_lo[wave][j];
+                if (pos < capacity) keys[pos] = key;
+                for (int q = 0; q < passes; q++) {
+                    const int bit = sort_begin + 8 * q, nb = min(8, sort_end - bit);
+                    atomicAdd(&lh[q * 256 + (uint32_t)((key >> bit) & ((1u << nb) - 1u))], 1u);
+                }
+            } else if (pos < capacity) {
+                keys[pos] = ((uint64_t)tile << 32) | s_lo[wave][j];
+                vals[pos] = s_hi[wave][j];
             }
+        }
+        __builtin_amdgcn_wave_barrier();           // the next K1 workgroup overwrites this wave's LDS rows
+    }
+    if (PACKED) {
+        __syncthreads();
+        for (int i = (int)tid; i < passes * 256; i += 256)
+            if (lh[i]) atomicAdd(&hist[i], lh[i]);
     }
 }
 
@@ -92,9 +193,11 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
 // while it moves: they only look at its tile field, which all members share.
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
-lg_tile_ranges(uint32_t R, int tile_shift, int gid_bits, int drop, const uint64_t* keys /* == entries in the packed format */,
+lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, int drop, const uint64_t* keys /* == entries in the packed format */,
                const uint32_t* __restrict__ vals_sorted, uint64_t* entries, uint64_t* scratch, uint2* __restrict__ ranges)
 {
+    if (counters[0] != 0u) return;                 // view aborted (capacity-bounded forward)
+    const uint32_t R = counters[3];                // the grid is sized for the capacity; the instance count lives on the device
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const uint64_t key = keys[i];

@@ -174,8 +174,8 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
 // batch back to front, evaluating an entry only on the sub-blocks it overlaps (scalar branches on the
 // mask).  The 9 partials are reduced with permlane32/16 swaps + row DPP adds (8 values packed into two
 // registers: ~20 instructions instead of 54), parked in LDS, and written once per batch as 48-byte gradient
-// rows (lane j owns entry j): part [R][12] floats (9 used) = dmean2D px x,y | dA dB dC | dopacity | drgb,
-// addressed by the instance's pre-sort slot -- no atomics, every row written exactly once.
+// rows (lane j owns entry j): part [R][12] floats (9 used) = the five pixel-offset moments | sum t | drgb (see
+// lg_rows_to_grads), addressed by the instance's pre-sort slot -- no atomics, every row written exactly once.
 typedef unsigned lg_u2v __attribute__((ext_vector_type(2)));
 
 // combine two registers into one: lower 32 lanes = 32-lane partial sums of a, upper 32 lanes = of b
@@ -216,11 +216,21 @@ __device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* 
     if (lane == 63u) dst[8] = w8;
 }
 
-// One (pixel, Gaussian) step of the back-to-front replay.  EXACT = canonical arithmetic (same sequence as
-// the oracle); otherwise hardware exp / rcp and contraction allowed (training path, 1e-4 contract).
+// Gradient rows hold MOMENTS, not finished gradients.  With t = G * dL/dalpha per (pixel, Gaussian) pair, dx = x_g - px:
+//   p[0] = sum t dx   p[1] = sum t dy   p[2] = sum t dx^2   p[3] = sum t dx dy   p[4] = sum t dy^2   p[5] = sum t
+//   p[6..8] = sum alpha T dL/dC_c
+// The published per-pair expressions are linear in these sums with per-Gaussian coefficients (conic, opacity):
+//   dL/dmean2D.x = op (2 ha p0 + nb p1)   dL/dmean2D.y = op (2 hc p1 + nb p0)     (ha = -A/2, nb = -B, hc = -C/2)
+//   dL/dA = -op p2 / 2   dL/dB = -op p3   dL/dC = -op p4 / 2   dL/dopacity = p5
+// so K9 applies them ONCE per Gaussian after summing its rows (lg_rows_to_grads) instead of K7 once per pair: 9 VALU
+// instructions per pair evaluation instead of 19 for this part, same values up to float rounding.
+// (lg_rows_to_grads lives in lg_math.h)
+
+// One (pixel, Gaussian) step of the back-to-front replay.  EXACT = canonical arithmetic for every include / exclude
+// decision (same sequence as the oracle); otherwise hardware exp / rcp and contraction allowed (training path, 1e-4 contract).
 template <bool EXACT>
-__device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const float4& c, float pxf, float pyf, float& T, float T_final,
-                                         float g0, float g1, float g2, float bg_dot, float& a0, float& a1, float& a2, float& last_alpha,
+__device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const float4& c, float pxf, float pyf, float& T, float Tfb,
+                                         float g0, float g1, float g2, float& a0, float& a1, float& a2, float& last_alpha,
                                          float& lc0, float& lc1, float& lc2, float (&p)[9])
 {
     const float dx = a.x - pxf, dy = a.y - pyf;
@@ -231,8 +241,8 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
         const float G = lg_exp(power);
         const float alpha = fminf(LG_ALPHA_MAX, op * G);
         if (alpha < LG_ALPHA_MIN) return false;
-        const float A = -2.0f * a.z, B = -a.w, Cc = -2.0f * b.x;
-        T = T / (1.0f - alpha);
+        const float om = 1.0f - alpha;
+        T = T / om;
         const float dch = alpha * T;
         const float c0 = b.z, c1 = b.w, c2 = c.x;
         a0 = last_alpha * lc0 + (1.0f - last_alpha) * a0;
@@ -242,15 +252,15 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
         float dL_dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
         dL_dalpha = dL_dalpha * T;
         last_alpha = alpha;
-        dL_dalpha = dL_dalpha + (-T_final / (1.0f - alpha)) * bg_dot;
-        const float dL_dG = op * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        p[0] += dL_dG * (-gdx * A - gdy * B);
-        p[1] += dL_dG * (-gdy * Cc - gdx * B);
-        p[2] += -0.5f * gdx * dx * dL_dG;
-        p[3] += -gdx * dy * dL_dG;
-        p[4] += -0.5f * gdy * dy * dL_dG;
-        p[5] += G * dL_dalpha;
+        dL_dalpha = dL_dalpha + (-Tfb / om);
+        const float t = G * dL_dalpha;
+        const float tdx = t * dx, tdy = t * dy;
+        p[0] += tdx;
+        p[1] += tdy;
+        p[2] += tdx * dx;
+        p[3] += tdx * dy;
+        p[4] += tdy * dy;
+        p[5] += t;
         p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
         return true;
     }
@@ -258,12 +268,12 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
 }
 
 // Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
-// the whole sequence and invalid lanes are neutralised by zeroing dL/dalpha and the colour weight and by
+// the whole sequence and invalid lanes are neutralised by zeroing t and the colour weight and by
 // selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
 // early-out when no lane of the 8x8 block takes the entry -- `if (__ballot(ok) == 0) return` -- was measured: 0.946 vs
 // 0.927 ms; blocks that pass the box test almost always have a contributing pixel.)
 __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
-                                              float& T, float T_final, float g0, float g1, float g2, float bg_dot, float& a0, float& a1,
+                                              float& T, float Tfb, float g0, float g1, float g2, float& a0, float& a1,
                                               float& a2, float (&p)[9])
 {
 #pragma clang fp contract(fast)
@@ -274,32 +284,32 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
     const float op = b.y;
     const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, pe); // same decisions as the forward
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
-    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (0*c + 1*a = a)
-    // and dch = 0, so four of the seven selects of a naive branch-free form disappear (v_cndmask / v_cmp / v_min cost
-    // ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).  T keeps its select: rcp(1.0) need not be exactly 1.
+    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (a + 0 * d = a)
+    // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
     const float am = ok ? alpha : 0.0f;
-    const float om = 1.0f - am;
-    const float inv = __builtin_amdgcn_rcpf(om);
+    const float inv = __builtin_amdgcn_rcpf(1.0f - am);
     const float Tn = T * inv;
-    const float c0 = b.z, c1 = b.w, c2 = c.x;
-    // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence)
-    const float dch = am * Tn;
-    float dL_dalpha = ((c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2) * Tn - (T_final * inv) * bg_dot;
-    dL_dalpha = ok ? dL_dalpha : 0.0f;
+    // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence);
+    // d = c - a serves both dL/dalpha and the update a += am * d
+    const float d0 = b.z - a0, d1 = b.w - a1, d2 = c.x - a2;
+    const float dL_dalpha = (d0 * g0 + d1 * g1 + d2 * g2) * Tn - Tfb * inv;      // Tfb = T_final * (bg . dL/dC), per pixel
+    const float t = ok ? G * dL_dalpha : 0.0f;
+#ifdef LG_K7_NO_TSEL
+    T = Tn;                                   // relies on v_rcp_f32(1.0) == 1.0 exactly (am = 0 on invalid lanes)
+#else
     T = ok ? Tn : T;
-    a0 = am * c0 + om * a0;
-    a1 = am * c1 + om * a1;
-    a2 = am * c2 + om * a2;
-    const float dL_dG = op * dL_dalpha;
-    const float gdx = G * dx, gdy = G * dy;
-    // with ha = -A/2, nb = -B, hc = -C/2:  -gdx*A - gdy*B = 2*ha*gdx + nb*gdy
-    p[0] += dL_dG * (2.0f * a.z * gdx + a.w * gdy);
-    p[1] += dL_dG * (2.0f * b.x * gdy + a.w * gdx);
-    const float hg = -0.5f * dL_dG;
-    p[2] += hg * gdx * dx;
-    p[3] -= dL_dG * gdx * dy;
-    p[4] += hg * gdy * dy;
-    p[5] += G * dL_dalpha;
+#endif
+    a0 = am * d0 + a0;
+    a1 = am * d1 + a1;
+    a2 = am * d2 + a2;
+    const float dch = am * Tn;
+    const float tdx = t * dx, tdy = t * dy;
+    p[0] += tdx;
+    p[1] += tdy;
+    p[2] += tdx * dx;
+    p[3] += tdx * dy;
+    p[4] += tdy * dy;
+    p[5] += t;
     p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
     return ok;
 }
@@ -321,7 +331,7 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
     const size_t HW = (size_t)H * W;
     const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
 
-    float pxf[4], pyf[4], T[4], Tfin[4], g0[4], g1[4], g2[4], bgd[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
+    float pxf[4], pyf[4], T[4], Tfb[4], g0[4], g1[4], g2[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
     uint32_t last[4];
     uint32_t wmax = 0;
 #pragma unroll
@@ -330,13 +340,12 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
         const bool inside = pxi < W && pyi < H;
         const size_t pid = (size_t)pyi * W + pxi;
         pxf[s] = (float)pxi; pyf[s] = (float)pyi;
-        Tfin[s] = inside ? final_T[pid] : 0.0f;
-        T[s] = Tfin[s];
+        T[s] = inside ? final_T[pid] : 0.0f;
         last[s] = inside ? n_contrib[pid] : 0u;
         g0[s] = inside ? dL_dpix[pid] : 0.0f;
         g1[s] = inside ? dL_dpix[HW + pid] : 0.0f;
         g2[s] = inside ? dL_dpix[2 * HW + pid] : 0.0f;
-        bgd[s] = bgr * g0[s] + bgg * g1[s] + bgb * g2[s];
+        Tfb[s] = T[s] * (bgr * g0[s] + bgg * g1[s] + bgb * g2[s]);   // T_final * (bg . dL/dC): the background term of dL/dalpha
         a0[s] = a1[s] = a2[s] = la[s] = lc0[s] = lc1[s] = lc2[s] = 0.0f;
         wmax = max(wmax, last[s]);
     }
@@ -393,10 +402,10 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
                         if (m & (1u << s)) {
                             if (EXACT) {
                                 if (rel <= last[s])
-                                    contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s], a1[s], a2[s],
+                                    contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s],
                                                               la[s], lc0[s], lc1[s], lc2[s], p);
                             } else {
-                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfin[s], g0[s], g1[s], g2[s], bgd[s], a0[s],
+                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s],
                                                          a1[s], a2[s], p);
                             }
                         }

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -79,20 +80,15 @@ struct GeomView {
     float4* rec;        // [N][LG_REC_F4]  blend record {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
     float4* aux;        // [N][2]  backward record {cov3D[0..3]} {cov3D[4], cov3D[5], clamp-bits, -}
     uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
-    uint32_t* touched;  // [N]
-    uint32_t* offsets;  // [N] inclusive scan of touched
-    uint32_t* counters; // [16]: 1 = prefiltered violation, 2 = largest depth bit pattern
-    uint32_t* blk_dmax; // [ceil(N/64)] per-workgroup largest depth bit pattern (reduced by lg_reduce_dmax)
-    void* scan_temp; size_t scan_temp_bytes;
+    uint32_t* touched;  // [N]  instance count per Gaussian (K1)
+    uint32_t* offsets;  // [N]  inclusive scan of touched (written by K3; K9 derives the slot base from it)
+    uint32_t* counters; // [16] per-view device words: 0 = abort flags, 1 = prefiltered violation, 2 = largest depth bit
+                        //      pattern, 3 = instance count R (all written by lg_scan_blocks)
+    uint32_t* blk_dmax; // [ceil(N/64)] per-K1-workgroup largest depth bit pattern (bit 31: prefiltered violation)
+    uint32_t* blk_sum;  // [ceil(N/64)] per-K1-workgroup instance count
+    uint32_t* blk_off;  // [ceil(N/64)] its exclusive scan (lg_scan_blocks)
     size_t total;
 };
-
-static size_t scan_temp_bytes_for(int N)
-{
-    size_t bytes = 0;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, N);
-    return bytes;
-}
 
 static GeomView carve_geom(void* base, int N)
 {
@@ -108,43 +104,15 @@ static GeomView carve_geom(void* base, int N)
     g.offsets = (uint32_t*)take(n * 4);
     g.counters = (uint32_t*)take(64);
     g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
-    g.scan_temp_bytes = scan_temp_bytes_for((int)n);
-    g.scan_temp = take(g.scan_temp_bytes);
+    g.blk_sum = (uint32_t*)take(((n + 63) / 64) * 4);
+    g.blk_off = (uint32_t*)take(((n + 63) / 64) * 4);
     g.total = off;
     return g;
 }
 
-// K4: keys-only radix sort of the packed 64-bit keys (rocPRIM onesweep).  rocPRIM's tuned gfx950 configuration for
-// 8-byte keys is 512 threads x 12 keys per block; for the ~4 M instances of a view a sweep on MI355X measured
-// (sort ms at C3): 256x8 0.379, 256x12 0.310, 256x16 0.284, 512x6 0.290, 512x12 (rocPRIM default) 0.237, 512x16 0.238,
-// 1024x4 0.255, 1024x6 0.229, **1024x8 0.209**, 1024x10 0.241, 1024x12 0.256, 1024x16 0.218; 10 radix bits: 0.273.
-// -DLG_SORT_ROCPRIM_DEFAULT restores rocPRIM's own choice.
-#ifndef LG_SORT_BLOCK
-#define LG_SORT_BLOCK 1024
-#define LG_SORT_ITEMS 8
-#endif
-#ifndef LG_SORT_BITS
-#define LG_SORT_BITS 8
-#endif
-#ifdef LG_SORT_ROCPRIM_DEFAULT
-using lg_onesweep_config = rocprim::default_config;
-using lg_sort_config = rocprim::default_config;
-#else
-using lg_onesweep_config = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>,
-                                                               rocprim::kernel_config<LG_SORT_BLOCK, LG_SORT_ITEMS>, LG_SORT_BITS,
-                                                               rocprim::block_radix_rank_algorithm::match>;
-using lg_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, lg_onesweep_config>;
-#endif
+// K4: keys-only radix sort of the packed 64-bit keys: our own onesweep kernels (lg_sort.h).  Tile shape by a measured
+// sweep on MI355X at C3 (~4 M keys), -DLG_SORT_BLOCK / -DLG_SORT_ITEMS to change it.
 #include "lg_sort.h"
-static inline hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, uint64_t* keys_in, uint64_t* keys_out, unsigned n, unsigned begin_bit,
-                                      unsigned end_bit, hipStream_t stream)
-{
-#ifdef LG_SORT_ROCPRIM_HOST
-    return rocprim::radix_sort_keys<lg_sort_config>(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, stream);
-#else
-    return lg_onesweep_sort_keys<lg_onesweep_config>(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, stream);
-#endif
-}
 
 struct ImgView { float* final_T; uint32_t* n_contrib; size_t total; };
 static ImgView carve_img(void* base, int W, int H)
@@ -188,7 +156,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     v.keys_in = (uint64_t*)take(n * 8);
     size_t tb = 0;
     if (packed) {
-        (void)lg_sort_keys(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)n, 0, 64, nullptr);
+        tb = lg_sort_layout(n).total;
     } else {
         v.keys_tmp = (uint64_t*)take(n * 8);
         v.vals_in = (uint32_t*)take(n * 4);

@@ -327,6 +327,21 @@ struct LgGradOut {
     float rot[4];
 };
 
+// Gradient rows of the backward blend hold pixel-offset MOMENTS (lg_blend.h): m[0..4] = sum t {dx, dy, dx^2, dx dy, dy^2},
+// m[5] = sum t, with t = G dL/dalpha and dx = x_g - px; m[6..8] = dL/drgb.  The published per-pair expressions are linear in
+// them with per-Gaussian coefficients (ha = -A/2, nb = -B, hc = -C/2 of the conic, opacity op), applied here once per Gaussian:
+// acc = {dL/dmean2D.x, .y (pixel units), dL/dA, dL/dB, dL/dC, dL/dopacity, dL/drgb}, the input of lg_backward_geom.
+LG_HD void lg_rows_to_grads(const float* m, float ha, float nb, float hc, float op, float* acc)
+{
+    acc[0] = op * (2.0f * ha * m[0] + nb * m[1]);
+    acc[1] = op * (2.0f * hc * m[1] + nb * m[0]);
+    acc[2] = -0.5f * op * m[2];
+    acc[3] = -op * m[3];
+    acc[4] = -0.5f * op * m[4];
+    acc[5] = m[5];
+    acc[6] = m[6]; acc[7] = m[7]; acc[8] = m[8];
+}
+
 LG_HD void lg_backward_geom(const float* vm, const float* pm, float px, float py, float pz, const float* S /*cov3D*/,
                             const float* acc, int W, int H, float tanfovx, float tanfovy, LgGradOut& g)
 {

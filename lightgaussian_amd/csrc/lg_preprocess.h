@@ -127,8 +127,8 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    uint32_t touched = 0;
     if (i < N) {
-        uint32_t touched = 0;
         int radius = 0;
         if (vis) {
             radius = sp.radius;
@@ -198,7 +198,15 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, sh));
     // bit 31 (never set in the bit pattern of a positive depth): a prefiltered violation in this workgroup
-    if (lane == 0) g.blk_dmax[blockIdx.x] = dmax | (__ballot(violation) ? 0x80000000u : 0u);
+    // ... and its instance count: lg_scan_blocks scans these words (one per 64 Gaussians) instead of a device-wide scan of N
+    uint32_t tsum = touched;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, sh);
+    const uint64_t any_violation = __ballot(violation);   // evaluated by the whole wave, not under the lane-0 branch below
+    if (lane == 0) {
+        g.blk_dmax[blockIdx.x] = dmax | (any_violation ? 0x80000000u : 0u);
+        g.blk_sum[blockIdx.x] = tsum;
+    }
 }
 
 
@@ -214,7 +222,8 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                  const int32_t* __restrict__ radii, const float4* __restrict__ aux, const uint32_t* __restrict__ touched,
+                  const int32_t* __restrict__ radii, const float4* __restrict__ rec, const float4* __restrict__ aux,
+                  const uint32_t* __restrict__ counters, const uint32_t* __restrict__ touched,
                   const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                   float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
@@ -228,7 +237,8 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    const bool vis = (i < N) && radii[i] > 0;
+    // counters[0] != 0: the forward aborted this view on the device (lg_forward_bounded overflow); there are no rows
+    const bool vis = (i < N) && radii[i] > 0 && counters[0] == 0u;
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;
     const int rowf = split ? 3 * (M - 1) : 3 * M;
@@ -274,16 +284,21 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
     if (vis) {
         // gather this Gaussian's gradient rows (one per tile instance) in slot order: deterministic, no atomics.
         // Splats with more than LG_COOP_ROWS instances were summed cooperatively by the whole wave (below).
-        float a[9];
+        float mo[9];
 #pragma unroll
-        for (int k9 = 0; k9 < 9; k9++) a[k9] = coop[k9];
+        for (int k9 = 0; k9 < 9; k9++) mo[k9] = coop[k9];
         if (my_t <= LG_COOP_ROWS) {
             for (uint32_t u = my_u0; u < my_u0 + my_t; u++) {
                 const float4* rp = part + 3 * (size_t)u;
                 const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-                a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w; a[8] += v2.x;
+                mo[0] += v0.x; mo[1] += v0.y; mo[2] += v0.z; mo[3] += v0.w; mo[4] += v1.x; mo[5] += v1.y; mo[6] += v1.z; mo[7] += v1.w; mo[8] += v2.x;
             }
         }
+        // the rows are pixel-offset moments (lg_blend.h): finish them with this Gaussian's conic and opacity, exactly the
+        // values the blend kernels used (its blend record)
+        const float4 q0 = rec[LG_REC_F4 * (size_t)i], q1 = rec[LG_REC_F4 * (size_t)i + 1];
+        float a[9];
+        lg_rows_to_grads(mo, q0.z, q0.w, q1.x, q1.y, a);
         const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
         const float4 x0 = aux[2 * (size_t)i], x1 = aux[2 * (size_t)i + 1];
         float S[6] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y };

@@ -125,6 +125,18 @@ lg_prune_mask_kernel(int N, uint32_t rank_score, const float* __restrict__ v_lis
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) mask[i] = v_list[i] <= thr ? 1 : 0;
 }
 
+// stand-alone select: out_value[0] = the rank-th smallest value; mask[i] = values[i] <= it (mask may be NULL)
+__global__ void __launch_bounds__(256)
+lg_select_finish_kernel(int N, uint32_t rank, const float* __restrict__ values, const LgSelect* __restrict__ st, uint8_t* __restrict__ mask,
+                        float* __restrict__ out_value)
+{
+    __shared__ uint32_t res[2];
+    const float thr = lg_order_key_inv(lg_select_resolve(st, rank, 4, res));
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_value[0] = thr;
+    if (!mask) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) mask[i] = values[i] <= thr ? 1 : 0;
+}
+
 // out[j] = ((rows[0][j] + rows[1][j]) + rows[2][j]) + ... : the reference's sequential in-place float adds over the views
 // (prune.py:144-155), one launch instead of V - 1 elementwise kernels.  Thread per column, rows streamed coalesced.
 __global__ void __launch_bounds__(256)

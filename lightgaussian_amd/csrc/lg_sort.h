@@ -1,112 +1,241 @@
-// lg_sort.h -- K4 driver: rocPRIM's onesweep radix-sort KERNELS (histogram + one decoupled-lookback pass per digit) behind
-// our own host loop.  rocprim::radix_sort_keys resets its lookback states and its ordered-block-id counter with two
-// hipMemsetAsync per pass because it reuses one buffer for all passes: 9 memsets ~ 45 us of a 0.17 ms sort of 4 M keys in
-// the kernel trace.  Here every pass has its own lookback states and counter, all cleared by ONE memset up front.
-// The kernels, their configuration machinery and the temp-storage types are rocPRIM's (rocprim::detail, ROCm 7.x headers);
-// -DLG_SORT_ROCPRIM_HOST falls back to the plain library call.
+// lg_sort.h -- K4: hand-written onesweep LSD radix sort of 64-bit keys (keys only, stable, ascending) for gfx950 / wave64.
+// Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
+//
+// One launch per 8-bit digit ("chained scan with decoupled look-back", the onesweep scheme): a workgroup takes a tile of
+// LG_SORT_BLOCK x LG_SORT_ITEMS keys in ticket order, ranks them by digit, publishes its 256 per-digit counts, resolves
+// the counts of all earlier tiles by looking back through their published states, and scatters its keys -- reordered in
+// LDS first so that each digit's run leaves as contiguous 8-byte stores.  The digit histograms of ALL passes are not
+// computed by a pass over the keys: K3 (lg_duplicate) has every key in registers when it emits it and accumulates them
+// there (lg_sort_hist is the stand-alone form for other callers).
+//
+//   ranking      per wave and item (64 consecutive keys): lanes with equal digits find each other with 8 ballots
+//                ("match"), the lowest of them bumps the wave's 16-bit LDS counter of that digit; rank = old counter +
+//                number of equal lanes below.  Key order (wave, item, lane) = index order, so the sort is stable.
+//   look-back    thread d owns digit d: state word = 2 flag bits | 30-bit count, one relaxed agent-scope store / load
+//                per word (the word is its own payload: no fence).  Tiles are numbered by an atomic ticket, so every
+//                predecessor a tile waits for is already running: no deadlock whatever the dispatch order.
+//   LDS          keys 8 B x tile + 16-bit counters [waves][256] + three 256-word tables: 74 KB at 1024 x 8 (2 workgroups
+//                per CU), 38 KB at 512 x 8.
+// n < 2^30 keys (30-bit state payload); the device-side key count and abort flag come from `counters` (lg_host.h) so that
+// the capacity-bounded forward (lg_forward_bounded) needs no host round trip.
 #pragma once
 
-#include <rocprim/rocprim.hpp>
-#include <variant>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
+#ifndef LG_SORT_BLOCK
+#define LG_SORT_BLOCK 1024
+#endif
+#ifndef LG_SORT_ITEMS
+#define LG_SORT_ITEMS 8
+#endif
+#define LG_SORT_WAVES (LG_SORT_BLOCK / 64)
+#define LG_SORT_TILE (LG_SORT_BLOCK * LG_SORT_ITEMS)
+#define LG_SORT_MAX_PASSES 8 // 64 key bits / 8
+#define LG_SORT_FLAG_AGG 1u
+#define LG_SORT_FLAG_PREFIX 2u
+#define LG_SORT_VALUE_MASK 0x3FFFFFFFu
+static_assert(LG_SORT_BLOCK >= 256 && LG_SORT_BLOCK % 64 == 0, "one thread per digit needs >= 256 threads");
+static_assert(LG_SORT_ITEMS * 64 < 65536 && LG_SORT_TILE < 65536, "16-bit LDS counters");
+
+// temp-storage layout: [hist 8 x 256 u32][tickets 8 u32 (64 B)][states passes x tiles x 256 u32][keys_tmp n u64]
 struct LgSortLayout {
-    size_t hist_off, hist_tmp_off, lookback_off, ids_off, keys_tmp_off, total;
-    unsigned num_states;
+    size_t hist_off, ticket_off, state_off, keys_tmp_off, total;
+    unsigned tiles;
 };
-static const unsigned LG_SORT_MAX_PLACES = 8;   // 64 key bits / 8
-
-template <class Config>
-static LgSortLayout lg_sort_layout(size_t n, hipStream_t stream, hipError_t& err)
+static inline LgSortLayout lg_sort_layout(size_t n)
 {
-    using namespace rocprim::detail;
-    using config = wrapped_radix_sort_onesweep_config<Config, uint64_t, rocprim::empty_type>;
     LgSortLayout L{};
-    target_arch arch;
-    err = host_target_arch(stream, arch);
-    if (err != hipSuccess) return L;
-    const radix_sort_onesweep_config_params params = dispatch_target_arch<config, false>(arch);
-    const unsigned items_per_block = params.sort.block_size * params.sort.items_per_thread;
-    const unsigned radix_size = 1u << params.radix_bits_per_place;
-    L.num_states = radix_size * (unsigned)((n + items_per_block - 1) / items_per_block);
+    if (n == 0) n = 1;
+    L.tiles = (unsigned)((n + LG_SORT_TILE - 1) / LG_SORT_TILE);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
-    L.hist_off = take((size_t)radix_size * LG_SORT_MAX_PLACES * sizeof(unsigned));
-    L.hist_tmp_off = take((size_t)radix_size * sizeof(unsigned));
-    L.lookback_off = take((size_t)L.num_states * LG_SORT_MAX_PLACES * sizeof(onesweep_lookback_state));
-    L.ids_off = take((size_t)LG_SORT_MAX_PLACES * 64);
-    L.keys_tmp_off = take(n * sizeof(uint64_t));
+    L.hist_off = take((size_t)LG_SORT_MAX_PASSES * 256 * 4);
+    L.ticket_off = take(64);
+    L.state_off = take((size_t)LG_SORT_MAX_PASSES * L.tiles * 256 * 4);
+    L.keys_tmp_off = take(n * 8);
     L.total = off;
     return L;
 }
-
-// Stable ascending sort of the bits [begin_bit, end_bit) of n 64-bit keys; keys_in is preserved, result in keys_out.
-template <class Config>
-static hipError_t lg_onesweep_sort_keys(void* temp, size_t& temp_bytes, uint64_t* keys_in, uint64_t* keys_out, unsigned n,
-                                        unsigned begin_bit, unsigned end_bit, hipStream_t stream)
+// bytes at the start of the temp storage that must be zero before a sort with `passes` passes (hist, tickets, states)
+static inline size_t lg_sort_clear_bytes(const LgSortLayout& L, unsigned passes)
 {
-    using namespace rocprim::detail;
-    using key_type = uint64_t;
-    using value_type = rocprim::empty_type;
-    using config = wrapped_radix_sort_onesweep_config<Config, key_type, value_type>;
-    hipError_t err = hipSuccess;
-    const LgSortLayout L = lg_sort_layout<Config>(n ? n : 1, stream, err);
-    if (err != hipSuccess) return err;
+    return L.state_off + (size_t)passes * L.tiles * 256 * 4;
+}
+
+// Stand-alone digit histograms of all passes (callers that do not produce the keys themselves; the rasterizer's K3 does).
+__global__ void __launch_bounds__(256)
+lg_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int begin_bit, int end_bit, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t lh[LG_SORT_MAX_PASSES * 256];
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    for (int i = threadIdx.x; i < passes * 256; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < passes; p++) {
+            const int bit = begin_bit + 8 * p, nb = min(8, end_bit - bit);
+            atomicAdd(&lh[p * 256 + (uint32_t)((k >> bit) & ((1u << nb) - 1u))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * 256; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+__device__ __forceinline__ uint32_t lg_ld_state(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One digit pass.  counters (may be NULL): [0] != 0 aborts the view (capacity overflow, lg_forward_bounded), [3] = key
+// count; with counters == NULL the count is n_arg.  hist = this pass's 256 global digit counts, ticket / states = this
+// pass's ticket word and state array (zeroed by the caller's one memset).
+__global__ void __launch_bounds__(LG_SORT_BLOCK)
+lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ counters, uint32_t n_arg,
+                 int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ states)
+{
+    __shared__ uint64_t stage[LG_SORT_TILE];
+    __shared__ unsigned short wcnt[LG_SORT_WAVES][256];
+    __shared__ uint32_t lbase[256];   // position of digit d's run inside the tile
+    __shared__ uint32_t goff[256];    // global position of the run minus lbase (wrap-around arithmetic)
+    __shared__ uint32_t wtot[8];      // cross-wave scan scratch: [0..3] tile counts, [4..7] global counts
+    __shared__ uint32_t s_tile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (counters && counters[0] != 0u) return;
+    const uint32_t n = counters ? counters[3] : n_arg;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (uint32_t i = tid; i < LG_SORT_WAVES * 256; i += LG_SORT_BLOCK) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t tile_base = (uint64_t)tile * LG_SORT_TILE;
+    if (tile_base >= n) return;                       // tiles beyond the (device-side) key count: nobody looks back at them
+    const uint32_t tile_n = (uint32_t)min((uint64_t)LG_SORT_TILE, (uint64_t)n - tile_base);
+    const uint32_t dmask = (1u << nbits) - 1u;
+
+    // ---- load + rank (per wave, item by item) ----
+    uint64_t key[LG_SORT_ITEMS];
+    uint32_t rnk[LG_SORT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < LG_SORT_ITEMS; k++) {
+        const uint32_t idx = (wave * LG_SORT_ITEMS + k) * 64u + lane;
+        key[k] = idx < tile_n ? src[tile_base + idx] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < LG_SORT_ITEMS; k++) {
+        const uint32_t idx = (wave * LG_SORT_ITEMS + k) * 64u + lane;
+        const bool valid = idx < tile_n;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        uint32_t prev = 0;
+        if (valid) prev = wcnt[wave][d];                                    // every peer reads the old count ...
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0u) wcnt[wave][d] = (unsigned short)(prev + (uint32_t)__popcll(peers));   // ... the lowest one bumps it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rnk[k] = prev + below;
+    }
+    __syncthreads();
+
+    // ---- per-digit: scan over the waves, look-back over the tiles, scans over the digits ----
+    uint32_t run = 0, gh = 0;
+    if (tid < 256) {
+#pragma unroll 4
+        for (int w = 0; w < LG_SORT_WAVES; w++) {
+            const uint32_t c = wcnt[w][tid];
+            wcnt[w][tid] = (unsigned short)run;                            // exclusive over the waves of this tile
+            run += c;
+        }
+        gh = hist[tid];
+        // publish the tile's aggregate before looking back: nobody ever waits for more than this store
+        if (tile > 0) lg_st_state(&states[(size_t)tile * 256 + tid], (LG_SORT_FLAG_AGG << 30) | run);
+        // exclusive scans over the 256 digits of (run, gh): wave scan + cross-wave carry through LDS
+        uint32_t ir = run, ig = gh;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t orr = __shfl_up(ir, s, 64), og = __shfl_up(ig, s, 64);
+            if ((int)lane >= s) { ir += orr; ig += og; }
+        }
+        if (lane == 63u) { wtot[wave] = ir; wtot[4 + wave] = ig; }
+        lbase[tid] = ir - run;                                              // wave-local exclusive; carry added below
+        goff[tid] = ig - gh;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t cr = 0, cg = 0;
+        for (uint32_t w = 0; w < wave; w++) { cr += wtot[w]; cg += wtot[4 + w]; }
+        const uint32_t lb = lbase[tid] + cr;                                // tile-local start of digit tid
+        const uint32_t gb = goff[tid] + cg;                                 // global start of digit tid (all tiles)
+        uint32_t excl = 0;
+        if (tile > 0) {
+            for (int64_t b = (int64_t)tile - 1; b >= 0; b--) {
+                uint32_t s = lg_ld_state(&states[(size_t)b * 256 + tid]);
+                while ((s >> 30) == 0u) { __builtin_amdgcn_s_sleep(1); s = lg_ld_state(&states[(size_t)b * 256 + tid]); }
+                excl += s & LG_SORT_VALUE_MASK;
+                if ((s >> 30) == LG_SORT_FLAG_PREFIX) break;
+            }
+        }
+        lg_st_state(&states[(size_t)tile * 256 + tid], (LG_SORT_FLAG_PREFIX << 30) | ((excl + run) & LG_SORT_VALUE_MASK));
+        lbase[tid] = lb;
+        goff[tid] = gb + excl - lb;
+    }
+    __syncthreads();
+
+    // ---- reorder inside the tile (LDS), then store each digit's run contiguously ----
+#pragma unroll
+    for (int k = 0; k < LG_SORT_ITEMS; k++) {
+        const uint32_t idx = (wave * LG_SORT_ITEMS + k) * 64u + lane;
+        if (idx < tile_n) {
+            const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
+            stage[lbase[d] + (uint32_t)wcnt[wave][d] + rnk[k]] = key[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < tile_n; q += LG_SORT_BLOCK) {
+        const uint64_t kq = stage[q];
+        const uint32_t d = (uint32_t)(kq >> shift) & dmask;
+        dst[(size_t)(goff[d] + q)] = kq;
+    }
+}
+
+// Stable ascending sort of bits [begin_bit, end_bit) of the 64-bit keys.  keys_in is preserved, the result lands in keys_out.
+// temp == NULL: size query.  hist_ready: the caller already accumulated the digit histograms into temp (+ L.hist_off) AFTER
+// clearing lg_sort_clear_bytes() bytes of temp -- the rasterizer's K3 does; otherwise this function clears and counts.
+// counters: optional device words {[0] abort flag, [3] key count} (see lg_onesweep_pass); n = capacity = upper bound of the count.
+static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, uint32_t n, int begin_bit,
+                               int end_bit, const uint32_t* counters, bool hist_ready, hipStream_t stream)
+{
+    const LgSortLayout L = lg_sort_layout(n);
     if (temp == nullptr) { temp_bytes = L.total; return hipSuccess; }
     if (n == 0) return hipSuccess;
-    if (temp_bytes < L.total || n >= (1u << 30)) return hipErrorInvalidValue;
-
-    target_arch arch;
-    ROCPRIM_RETURN_ON_ERROR(host_target_arch(stream, arch));
-    const radix_sort_onesweep_config_params params = dispatch_target_arch<config, false>(arch);
-    const unsigned items_per_block = params.sort.block_size * params.sort.items_per_thread;
-    const unsigned radix_size = 1u << params.radix_bits_per_place;
-    const unsigned places = (end_bit - begin_bit + params.radix_bits_per_place - 1) / params.radix_bits_per_place;
-    if (places == 0 || places > LG_SORT_MAX_PLACES) return hipErrorInvalidValue;
-
+    if (temp_bytes < L.total || n >= (1u << 30) || end_bit <= begin_bit || end_bit > 64) return hipErrorInvalidValue;
+    const int passes = (end_bit - begin_bit + 7) / 8;
     char* base = (char*)temp;
-    unsigned* hist = (unsigned*)(base + L.hist_off);
-    unsigned* hist_tmp = (unsigned*)(base + L.hist_tmp_off);
-    onesweep_lookback_state* lookback = (onesweep_lookback_state*)(base + L.lookback_off);
-    char* ids = base + L.ids_off;
-    key_type* keys_tmp = (key_type*)(base + L.keys_tmp_off);
-    value_type* no_values = nullptr;
-
-    // one clear for the lookback states and block-id counters of ALL passes (contiguous by construction)
-    ROCPRIM_RETURN_ON_ERROR(hipMemsetAsync(lookback, 0, (L.ids_off - L.lookback_off) + (size_t)LG_SORT_MAX_PLACES * 64, stream));
-    rocprim::identity_decomposer decomposer;
-    ROCPRIM_RETURN_ON_ERROR((radix_sort_onesweep_global_offsets<Config, false>(keys_in, no_values, hist, (unsigned)n, places, decomposer,
-                                                                               begin_bit, end_bit, stream, false)));
-    bool use_atomic = false;
-    ROCPRIM_RETURN_ON_ERROR(check_if_using_atomic_block_id(stream, use_atomic));
-    const auto variant = constexpr_value_variant<bool, false, true>::create(use_atomic);
-    const unsigned blocks = (n + items_per_block - 1) / items_per_block;
-    const unsigned full_blocks = n % items_per_block == 0 ? blocks : blocks - 1;
-
-    return std::visit(
-        [&](auto use_atomic_block_id) -> hipError_t {
-            using ordered_bid_type = block_id_wrapper<unsigned int, use_atomic_block_id>;
-            bool to_output = (places - 1) % 2 == 0;      // ping-pong between keys_tmp and keys_out so that the last pass lands in keys_out
-            bool from_input = true;
-            unsigned bit = begin_bit;
-            for (unsigned place = 0; place < places; place++, bit += params.radix_bits_per_place) {
-                const unsigned current_radix_bits = std::min(params.radix_bits_per_place, end_bit - bit);
-                auto ordered_bid = ordered_bid_type::create(ids + (size_t)place * 64);
-                onesweep_lookback_state* states = lookback + (size_t)place * L.num_states;
-                unsigned* offsets_in = hist + (size_t)place * radix_size;
-                const key_type* src = from_input ? keys_in : (to_output ? keys_tmp : keys_out);
-                key_type* dst = to_output ? keys_out : keys_tmp;
-                auto kernel = [=](auto arch_config) {
-                    static constexpr auto p = decltype(arch_config)::params;
-                    onesweep_iteration<p.sort.block_size, p.sort.items_per_thread, p.radix_bits_per_place, false, p.radix_rank_algorithm>(
-                        src, dst, no_values, no_values, n, offsets_in, hist_tmp, states, decomposer, bit, current_radix_bits, full_blocks,
-                        ordered_bid);
-                };
-                ROCPRIM_RETURN_ON_ERROR((execute_launch_plan<config, decltype(kernel), radix_sort_onesweep_sort_config_selector>(
-                    arch, kernel, dim3(blocks), dim3(params.sort.block_size), 0, stream)));
-                from_input = false;
-                to_output = !to_output;
-            }
-            return hipSuccess;
-        },
-        variant);
+    uint32_t* hist = (uint32_t*)(base + L.hist_off);
+    uint32_t* tickets = (uint32_t*)(base + L.ticket_off);
+    uint32_t* states = (uint32_t*)(base + L.state_off);
+    uint64_t* keys_tmp = (uint64_t*)(base + L.keys_tmp_off);
+    hipError_t e;
+    if (!hist_ready) {
+        if ((e = hipMemsetAsync(base, 0, lg_sort_clear_bytes(L, passes), stream)) != hipSuccess) return e;
+        const unsigned hb = (unsigned)std::min<size_t>(((size_t)n + 2047) / 2048, 1024);
+        lg_sort_hist<<<hb, 256, 0, stream>>>(keys_in, n, begin_bit, end_bit, hist);
+    }
+    bool to_output = (passes - 1) % 2 == 0;          // ping-pong so that the LAST pass writes keys_out
+    const uint64_t* src = keys_in;
+    for (int p = 0; p < passes; p++) {
+        const int bit = begin_bit + 8 * p, nb = std::min(8, end_bit - bit);
+        uint64_t* dst = to_output ? keys_out : keys_tmp;
+        lg_onesweep_pass<<<L.tiles, LG_SORT_BLOCK, 0, stream>>>(src, dst, counters, n, bit, nb, hist + (size_t)p * 256, tickets + p,
+                                                                 states + (size_t)p * L.tiles * 256);
+        src = dst;
+        to_output = !to_output;
+    }
+    return hipGetLastError();
 }

@@ -85,48 +85,76 @@ class _LeafView:
     get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
 
 
-def backward_over_views(model, cameras, targets, pipe, background, loss_fn, render_fn=None, streams=3):
+def backward_over_views(model, cameras, targets, pipe, background, loss_fn, render_fn=None, streams=3, host_threads=False):
     """Camera batch > 1 on ONE GPU: render the given views concurrently and accumulate
     d(sum_k loss_fn(image_k, target_k)) / d(raw parameters) into model.<param>.grad.
 
-    `streams` host threads, each with its own HIP stream, take the views round-robin (ctypes releases the GIL and the HIP
-    library is re-entrant per stream), so the VALU-bound blend kernels of one view overlap the memory-bound stages of
-    another (measured at 3M Gaussians, 1080p: 462 -> 546 views/s fwd+bwd with 3 views in flight).  Every thread
-    differentiates its own leaf view of the parameters (shared storage, no copies); the per-thread gradients are summed in
-    thread order afterwards, so the result is deterministic for a given `streams` (it differs from a one-by-one loop only
-    in float addition order).  Returns the list of per-view loss values (detached tensors, in view order)."""
-    import threading
+    ONE host thread issues view k onto HIP stream k % streams: the forwards go through lg_forward_bounded (option
+    sync_free: no read-back of the instance count, nothing on the path waits for the device), so the thread simply runs
+    ahead of the GPU and the VALU-bound blend kernels of one view overlap the memory-bound stages of another.  If a view did
+    not fit its binning capacity (reported on the device, checked once per batch) the whole batch is redone on the exact
+    path.  host_threads=True is the round-1 scheme (one host thread per stream, exact forwards, each thread blocked in its
+    own read-back).  Every stream differentiates its own leaf view of the parameters (shared storage, no copies); the
+    per-stream gradients are summed in stream order afterwards, so the result is deterministic for a given `streams` (it
+    differs from a one-by-one loop only in float addition order).  Returns the per-view loss values (detached, view order)."""
+    from . import rasterizer
     from .gaussian_renderer import render
     render_fn = render_fn or render
     dev = model._xyz.device
     K = max(1, min(int(streams), len(cameras)))
     main = torch.cuda.current_stream(dev)
     pool = [torch.cuda.Stream(device=dev) for _ in range(K)]
-    views = [_LeafView(model) for _ in range(K)]
-    losses = [None] * len(cameras)
-    errors = []
 
-    def work(w):
-        try:
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(pool[w]):
-                pool[w].wait_stream(main)
-                for k in range(w, len(cameras), K):
-                    loss = loss_fn(render_fn(cameras[k], views[w], pipe, background)["render"], targets[k])
-                    loss.backward()
-                    losses[k] = loss.detach()
-        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
-            errors.append(e)
+    def one(w, k, view):
+        loss = loss_fn(render_fn(cameras[k], view, pipe, background)["render"], targets[k])
+        loss.backward()
+        return loss.detach()
 
-    threads = [threading.Thread(target=work, args=(w,)) for w in range(K)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    for st in pool:
-        main.wait_stream(st)
+    def issue_all(views):
+        losses = [None] * len(cameras)
+        if host_threads:
+            import threading
+            errors = []
+
+            def work(w):
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(pool[w]):
+                        pool[w].wait_stream(main)
+                        for k in range(w, len(cameras), K):
+                            losses[k] = one(w, k, views[w])
+                except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                    errors.append(e)
+
+            threads = [threading.Thread(target=work, args=(w,)) for w in range(K)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+        else:
+            for st in pool:
+                st.wait_stream(main)
+            for k in range(len(cameras)):
+                with torch.cuda.stream(pool[k % K]):
+                    losses[k] = one(k % K, k, views[k % K])
+        for st in pool:
+            main.wait_stream(st)
+        return losses
+
+    prev = rasterizer._OPTIONS["sync_free"]
+    rasterizer.set_option("sync_free", not host_threads)
+    try:
+        rasterizer.pending_status()                       # forget forwards issued by earlier callers
+        views = [_LeafView(model) for _ in range(K)]
+        losses = issue_all(views)
+        if rasterizer.pending_overflow():                 # a view outgrew its capacity: redo the batch, exact forwards
+            rasterizer.set_option("sync_free", False)
+            views = [_LeafView(model) for _ in range(K)]
+            losses = issue_all(views)
+    finally:
+        rasterizer.set_option("sync_free", prev)
     for n in _RAW:
         p = getattr(model, n)
         total = None

@@ -61,11 +61,35 @@ def prune_mask_select(percent, import_score):
     return (import_score <= value_nth_percentile).squeeze()
 
 
-def prune_epilogue(gaussians, imp_list, v_pow, percent):
-    """calculate_v_imp_score (prune.py:112-128) + the mask of prune_gaussians (scene/gaussian_model.py:776-782) in one
-    device-resident pass of the HIP library (lg_prune_epilogue: two radix selects, no sort, no host read-back).
-    Returns (v_list [N] float32, mask [N] bool, thresholds [2] = {kth volume, score threshold}); same values as
-    calculate_v_imp_score(...) / prune_mask(percent, v_list).  CUDA/HIP tensors only -- no fallback."""
+def _select_mask(values, rank, want_mask=True):
+    """rank-th smallest element (0-based) of a 1-D float32 device tensor by the HIP radix select (lg_select_mask: four 8-bit
+    histogram passes, no sort, no host read-back) and, optionally, mask = values <= that element.  Returns (value [1], mask)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = values.shape[0]
+    dev = values.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev) if want_mask else None
+    scratch = torch.empty(lib.lg_prune_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.check(lib.lg_select_mask(n, values.data_ptr(), int(rank), None if mask is None else mask.data_ptr(), out.data_ptr(),
+                                  scratch.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out, mask
+
+
+def prune_epilogue(gaussians, imp_list, v_pow, percent, fused_pow=False):
+    """calculate_v_imp_score (prune.py:112-128) + the mask of prune_gaussians (scene/gaussian_model.py:776-782), device
+    resident: both order statistics are HIP radix SELECTS (no sort, no host read-back of the thresholds).
+    Returns (v_list [N] float32, mask [N] bool, thresholds [2] = {kth volume, score threshold}).
+
+    fused_pow=False (default): the two arithmetic steps between the selects -- torch.prod(scaling, 1) and
+        torch.pow(volume / kth, v_pow) * imp_list -- are evaluated by the SAME torch ops the reference runs, so v_list and the
+        mask are bit-identical to calculate_v_imp_score(...) / prune_mask(percent, v_list) (Hamming distance 0, asserted in
+        tests/test_gpu_prune_epilogue.py); a select returns exactly the element a sort puts at that index.
+    fused_pow=True: one library call (lg_prune_epilogue) that also evaluates powf(volume / kth, v_pow) * imp in the kernel.
+        Its v_list is within 1 ulp of torch.pow's (the device powf and torch's pow kernel round differently in the last
+        bit), so elements exactly at the threshold can fall on the other side: NOT the reference's mask, bit for bit.
+    CUDA/HIP tensors only -- no fallback."""
     import ctypes as C
     from . import _lib
     from . import rasterizer
@@ -75,8 +99,20 @@ def prune_epilogue(gaussians, imp_list, v_pow, percent):
     if not (scaling.is_cuda and imp.is_cuda):
         raise RuntimeError("prune_epilogue runs on the MI355X HIP library only (no CPU fallback)")
     N = scaling.shape[0]
+    if N <= 0:
+        raise Exception("prune epilogue needs N >= 1 (the reference indexes an empty sort)")
     if imp.shape[0] != N:
         raise ValueError(f"imp_list has {imp.shape[0]} entries for {N} Gaussians")
+    if not (0.0 <= float(percent) <= 1.0):
+        raise Exception("prune_percent must be in [0, 1]")
+    if not fused_pow:
+        with torch.no_grad():
+            volume = torch.prod(scaling, dim=1)                              # prune.py:120
+            index = int(N * 0.9)                                             # prune.py:122: element `index` of the DESCENDING sort
+            kth, _ = _select_mask(volume, N - 1 - min(index, N - 1), want_mask=False)
+            v_list = torch.pow(volume / kth[0], v_pow) * imp                 # prune.py:126-127, the reference's own ops
+            thr, mask = _select_mask(v_list, int(float(percent) * (N - 1)))  # scene/gaussian_model.py:778-781
+        return v_list, mask.bool(), torch.cat((kth, thr))
     lib = _lib.load()
     dev = scaling.device
     v_list = torch.empty(N, dtype=torch.float32, device=dev)
@@ -134,95 +170,155 @@ def prune_list(gaussians, scene, pipe, background, count_fn=count_render):
 
 
 def shard_bounds(num_views, world_size, rank):
-    """Contiguous block of the view SEQUENCE (sequence index s <-> cameras[V-1-s]) owned by `rank`."""
+    """Contiguous block of a view sequence owned by `rank` (plain partition helper; the significance pass itself uses the
+    block-cyclic schedule of round_views so that its memory does not grow with the number of views)."""
     return (num_views * rank) // world_size, (num_views * (rank + 1)) // world_size
 
 
-def _count_views(seq, lo, hi, gaussians, pipe, background, count_fn, N, ncols, streams):
-    """count_fn over seq[lo:hi].  Returns (count_sum int32 [N], per_view fp32 [hi-lo, ncols]) with per_view[k, :N] the
-    score vector of view lo+k.  With streams > 1 the views are rendered by that many host threads, each on its own HIP
-    stream (ctypes releases the GIL; the library is re-entrant per stream): the VALU-bound blend of one view overlaps the
-    memory-latency-bound projection and the radix sort of another.  Results do not depend on the schedule: counts are
-    integers and every view's scores land in their own row, to be summed in the reference's order afterwards."""
-    dev = gaussians.get_xyz.device
-    nv = max(hi - lo, 0)
-    per_view = torch.zeros((nv, ncols), dtype=torch.float32, device=dev)
-    streams = max(1, min(int(streams), nv)) if nv else 1
-    if streams == 1:
-        count_sum = torch.zeros(N, dtype=torch.int32, device=dev)
-        with torch.no_grad():
-            for k in range(nv):
-                pkg = count_fn(seq[lo + k], gaussians, pipe, background)
-                count_sum += pkg["gaussians_count"].detach().to(torch.int32)
-                per_view[k, :N] = pkg["important_score"].detach()
-        return count_sum, per_view
-    import threading
-    main = torch.cuda.current_stream(dev)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(streams)]
-    partial = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(streams)]
-    errors = []
+def num_rounds(num_views, world_size, block):
+    return (num_views + block * world_size - 1) // (block * world_size)
 
-    def work(w):
+
+def round_views(num_views, world_size, rank, block, t):
+    """Sequence indices [lo, hi) rendered by `rank` in round t: round t covers the next block*world views of the reference's
+    sequence, `block` consecutive ones per rank in rank order -- so the views of a round, concatenated over the ranks, are in
+    sequence order and a running sum can absorb them round by round (memory O(block * N), not O(V * N))."""
+    base = t * block * world_size + rank * block
+    return min(base, num_views), min(base + block, num_views)
+
+
+class _ViewRunner:
+    """Renders lists of views with count_fn, `streams` views in flight on as many HIP streams, so that the VALU-bound blend
+    of one view overlaps the memory-bound projection and the radix sort of another.  Default: ONE host thread issues view k
+    onto stream k % streams through the capacity-bounded forward (rasterizer option sync_free: no read-back of the instance
+    count, the thread runs ahead of the GPU); a view that outgrew its binning capacity contributes zeros on the device and is
+    re-rendered on the exact path after the one status check per block.  host_threads=True is the round-1 scheme (a host
+    thread per stream, each blocking in its own read-back).  Results do not depend on the schedule: counts are integers
+    (per-stream partial sums, added at the end) and every view's score vector lands in its own row of the caller's buffer,
+    to be summed in the reference's order afterwards."""
+
+    def __init__(self, gaussians, pipe, background, count_fn, N, streams, host_threads=False):
+        self.g, self.pipe, self.bg, self.count_fn, self.N = gaussians, pipe, background, count_fn, N
+        self.dev = gaussians.get_xyz.device
+        self.streams = max(1, int(streams)) if self.dev.type == "cuda" else 1
+        self.host_threads = host_threads
+        self.partial = [torch.zeros(N, dtype=torch.int32, device=self.dev) for _ in range(self.streams)]
+        self.pool = [torch.cuda.Stream(device=self.dev) for _ in range(self.streams)] if self.streams > 1 else []
+
+    def _one(self, view, w, rows, k):
+        pkg = self.count_fn(view, self.g, self.pipe, self.bg)
+        self.partial[w] += pkg["gaussians_count"].detach().to(torch.int32)
+        rows[k, :self.N] = pkg["important_score"].detach()
+
+    def run(self, views, rows):
+        """rows[k, :N] = important_score of views[k]; gaussians_count accumulates into the partial sums."""
+        nv = len(views)
+        if nv == 0:
+            return
+        if self.streams == 1 or nv == 1:
+            with torch.no_grad():
+                for k in range(nv):
+                    self._one(views[k], 0, rows, k)
+            return
+        main = torch.cuda.current_stream(self.dev)
+        K = min(self.streams, nv)
+        if self.host_threads:
+            import threading
+            errors = []
+
+            def work(w):
+                try:
+                    torch.cuda.set_device(self.dev)
+                    with torch.cuda.stream(self.pool[w]), torch.no_grad():
+                        self.pool[w].wait_stream(main)    # frozen getters / the running sum were produced on `main`
+                        for k in range(w, nv, K):
+                            self._one(views[k], w, rows, k)
+                except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                    errors.append(e)
+
+            threads = [threading.Thread(target=work, args=(w,)) for w in range(K)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            for st in self.pool[:K]:
+                main.wait_stream(st)
+            return
+        from . import rasterizer
+        prev = rasterizer._OPTIONS["sync_free"]
+        rasterizer.set_option("sync_free", True)
         try:
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(pool[w]), torch.no_grad():
-                pool[w].wait_stream(main)                 # the frozen getters / zeroed buffers were produced on `main`
-                for k in range(w, nv, streams):
-                    pkg = count_fn(seq[lo + k], gaussians, pipe, background)
-                    partial[w] += pkg["gaussians_count"].to(torch.int32)
-                    per_view[k, :N] = pkg["important_score"]
-        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
-            errors.append(e)
+            rasterizer.pending_status()                   # forget forwards issued by earlier callers
+            for st in self.pool[:K]:
+                st.wait_stream(main)
+            with torch.no_grad():
+                for k in range(nv):
+                    with torch.cuda.stream(self.pool[k % K]):
+                        self._one(views[k], k % K, rows, k)
+            for st in self.pool[:K]:
+                main.wait_stream(st)
+            redo = rasterizer.pending_status()            # ONE host sync per block of views
+        finally:
+            rasterizer.set_option("sync_free", prev)
+        if len(redo) == nv and any(redo):
+            # an abandoned view added zeros to the counts and wrote a zero score row: render it again, exact forward
+            with torch.no_grad():
+                for k in range(nv):
+                    if redo[k]:
+                        self._one(views[k], 0, rows, k)
 
-    threads = [threading.Thread(target=work, args=(w,)) for w in range(streams)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    for st in pool:
-        main.wait_stream(st)
-    count_sum = partial[0]
-    for p in partial[1:]:
-        count_sum += p
-    return count_sum, per_view
+    def count_sum(self):
+        total = self.partial[0]
+        for p in self.partial[1:]:
+            total += p
+        return total
 
 
-def _ordered_sum(rows):
-    """acc = rows[0]; acc += rows[1]; ... : the reference's sequential in-place float adds (prune.py:144-155).
-    On the GPU one lg_ordered_sum launch (same additions, same order); CPU tensors (gloo tests) take the literal loop."""
-    if rows.is_cuda and rows.dtype == torch.float32 and rows.stride(1) == 1:
+def _ordered_sum(rows, out=None):
+    """out = rows[0]; out += rows[1]; ... : the reference's sequential in-place float adds (prune.py:144-155).  `out` may be
+    rows[0] itself (running sum kept in row 0).  On the GPU one lg_ordered_sum launch (same additions, same order); CPU
+    tensors (gloo tests) take the literal loop."""
+    if out is None:
+        out = torch.empty(rows.shape[1], dtype=rows.dtype, device=rows.device)
+    if rows.is_cuda and rows.dtype == torch.float32 and rows.stride(1) == 1 and out.is_contiguous():
         import ctypes as C
         from . import _lib
-        out = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
         _lib.check(_lib.load().lg_ordered_sum(rows.shape[0], rows.shape[1], rows.data_ptr(), rows.stride(0), out.data_ptr(),
                                               C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)))
         return out
-    acc = rows[0].clone()
+    if out.data_ptr() != rows[0].data_ptr():
+        out.copy_(rows[0])
     for s in range(1, rows.shape[0]):
-        acc += rows[s]
-    return acc
+        out += rows[s]
+    return out
 
 
 def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False,
-                       streams=3):
-    """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same
-    Gaussians; returns the same (gaussian_list, imp_list) on every rank.  Without an initialised process
-    group (or at world size 1, unless force_collectives) it is the single-process loop with frozen getters.
-    streams: views in flight per rank (host threads x HIP streams, _count_views); 1 = the plain sequential loop.
-    Measured at C3 on one MI355X: 1 -> 1158, 2 -> 1061, 3 -> 1341, 4 -> 1326 views/s (identical results)."""
+                       streams=3, block=24, local_only=False, host_threads=False):
+    """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same Gaussians; returns the same
+    (gaussian_list, imp_list) on every rank, bit-identical to the reference loop (mode="ordered") for every world size.
+    Without an initialised process group (or at world size 1 unless force_collectives, or with local_only=True inside a
+    distributed job) it is the single-process loop with frozen getters.
+    streams: views in flight per rank (_ViewRunner: one host thread, sync-free forwards; host_threads=True = a thread per
+             stream with exact forwards); 1 = the plain sequential loop.
+    block:   views per rank per round.  The pass keeps a running sum and absorbs the views round by round in the reference's
+             order, so scratch memory is O(block * N) floats per rank whatever the number of views (the reference's loop is
+             O(N); the first version of this function held all V score vectors, O(V * N)).
+    Measured at C3 on one MI355X: streams 1 -> 1158, 2 -> 1061, 3 -> 1341, 4 -> 1326 views/s (identical results)."""
     from . import rasterizer
     prev = rasterizer._OPTIONS["skip_color_in_count"]
     rasterizer.set_option("skip_color_in_count", True)   # the pass discards the images: do not read 192 B of SH per Gaussian per view
     try:
-        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams)
+        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, max(1, int(block)),
+                                   local_only, host_threads)
     finally:
         rasterizer.set_option("skip_color_in_count", prev)
 
 
-def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams):
-    distributed = dist.is_available() and dist.is_initialized()
+def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, block, local_only, host_threads):
+    distributed = dist.is_available() and dist.is_initialized() and not local_only
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     if mode not in ("ordered", "allreduce"):
@@ -233,31 +329,143 @@ def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_f
     seq = cams[::-1]  # sequence order of the reference loop (pop() from the end)
     N = gaussians.get_xyz.shape[0]
     dev = gaussians.get_xyz.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    runner = _ViewRunner(gaussians, pipe, background, count_fn, N, streams, host_threads)
     if world == 1 and not (distributed and force_collectives):
-        if not gaussians.get_xyz.is_cuda or streams <= 1 or V < 2:
-            return prune_list(gaussians, scene, pipe, background, count_fn)
-        count_sum, per_view = _count_views(seq, 0, V, gaussians, pipe, background, count_fn, N, N, streams)
-        # prune.py:136-141: the first view's own tensors are the accumulators (count dtype = what the rasterizer returns)
-        return count_sum, _ordered_sum(per_view)
+        if V == 0:
+            raise IndexError("pop from empty list")     # what the reference's viewpoint_stack.pop() raises
+        # rows[0] = running sum.  It starts at +0: 0 + s == s bit for bit (scores are sums of non-negative weights), so the
+        # result equals the reference's "first view's tensor is the accumulator" (prune.py:136-141)
+        rows = torch.zeros((min(block, V) + 1, N), **f32)
+        for c0 in range(0, V, block):
+            views = seq[c0:c0 + block]
+            runner.run(views, rows[1:])
+            _ordered_sum(rows[:1 + len(views)], out=rows[0])
+        return runner.count_sum(), rows[0].clone()
 
-    lo, hi = shard_bounds(V, world, rank)
-    chunk = (N + world - 1) // world
-    count_sum, per_view = _count_views(seq, lo, hi, gaussians, pipe, background, count_fn, N, world * chunk,
-                                       streams if gaussians.get_xyz.is_cuda else 1)
+    chunk = (N + world - 1) // world                   # Gaussian slice owned by each rank in the ordered exchange
+    # rows[1:] = my views of the current round (columns >= N stay zero); rows[0] = running local sum (mode "allreduce")
+    rows = torch.zeros((block + 1, world * chunk), **f32)
+    if mode == "ordered":
+        recv = torch.zeros((1 + block * world, chunk), **f32)   # row 0 = running sum of MY slice over all views so far
+    for t in range(num_rounds(V, world, block)):
+        spans = [round_views(V, world, r, block, t) for r in range(world)]
+        sizes = [hi - lo for lo, hi in spans]
+        lo, hi = spans[rank]
+        mine = hi - lo
+        runner.run(seq[lo:hi], rows[1:])
+        if mode == "allreduce":
+            if mine:
+                _ordered_sum(rows[:1 + mine, :N], out=rows[0, :N])
+            continue
+        # ordered: rank j receives Gaussian slice j of every view of the round, in sequence order, and folds them into row 0
+        send = rows[1:1 + mine].view(mine, world, chunk).permute(1, 0, 2).contiguous().view(world * mine, chunk)
+        total = sum(sizes)
+        dist.all_to_all_single(recv[1:1 + total], send, output_split_sizes=sizes, input_split_sizes=[mine] * world, group=group)
+        _ordered_sum(recv[:1 + total], out=recv[0])
+    count_sum = runner.count_sum()
     dist.all_reduce(count_sum, op=dist.ReduceOp.SUM, group=group)
-
     if mode == "allreduce":
-        local_score = _ordered_sum(per_view[:, :N]) if hi > lo else torch.zeros(N, dtype=torch.float32, device=dev)
-        dist.all_reduce(local_score, op=dist.ReduceOp.SUM, group=group)
-        return count_sum, local_score
-
-    # ordered: rank j receives Gaussian slice j of every view, in sequence order
-    v_local = hi - lo
-    send = per_view.view(v_local, world, chunk).permute(1, 0, 2).contiguous().view(world * v_local, chunk)
-    sizes_out = [shard_bounds(V, world, r)[1] - shard_bounds(V, world, r)[0] for r in range(world)]
-    recv = torch.empty((V, chunk), dtype=torch.float32, device=dev)
-    dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=[v_local] * world, group=group)
-    acc = _ordered_sum(recv)
-    gathered = torch.empty(world * chunk, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gathered, acc, group=group)
+        score = rows[0, :N].contiguous()
+        dist.all_reduce(score, op=dist.ReduceOp.SUM, group=group)
+        return count_sum, score
+    gathered = torch.empty(world * chunk, **f32)
+    dist.all_gather_into_tensor(gathered, recv[0].contiguous(), group=group)
     return count_sum, gathered[:N].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# compaction after the prune (scene/gaussian_model.py:564-600)
+
+def compact_tensors(tensors, keep):
+    """[t[keep] for t in tensors] -- every tensor [N, ...] with the same N, keep a bool/uint8 [N] mask -- as ONE prefix scan of
+    the mask and ONE launch that moves the rows of all tensors (lg_compact_plan / lg_compact_rows), with a single 4-byte
+    read-back (the number of kept rows, which sizes the outputs); torch's boolean indexing runs nonzero() + a host sync per
+    tensor.  Row order is preserved: results equal t[keep] bit for bit.  HIP tensors only (no fallback); tensors whose rows
+    are not a multiple of 4 bytes are indexed by torch with the same destination map."""
+    import ctypes as C
+    from . import _lib
+    tensors = list(tensors)
+    if not tensors:
+        return []
+    N = tensors[0].shape[0]
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("compact_tensors runs on the MI355X HIP library only (no CPU fallback)")
+    if any(t.shape[0] != N or t.device != dev for t in tensors) or keep.shape[0] != N:
+        raise ValueError("compact_tensors: all tensors and the mask must share the first dimension and the device")
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    keep8 = keep.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
+    dest = torch.empty(N, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib.lg_compact_scratch_bytes(N), dtype=torch.uint8, device=dev)
+    _lib.check(lib.lg_compact_plan(N, keep8.data_ptr(), dest.data_ptr(), count.data_ptr(), scratch.data_ptr(), stream))
+    n_keep = int(count.item())                       # the one host read of the whole compaction
+    srcs = [t.detach().contiguous() for t in tensors]
+    outs = [torch.empty((n_keep,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in srcs]
+    native = [i for i, t in enumerate(srcs) if N > 0 and t[0].numel() * t.element_size() % 4 == 0 and t[0].numel() > 0]
+    for i in range(len(srcs)):
+        if i not in native and N > 0 and srcs[i][0].numel() > 0:
+            outs[i] = srcs[i][keep8.bool()]
+    for lo in range(0, len(native), 32):
+        part = native[lo:lo + 32]
+        n = len(part)
+        src_arr = (C.c_void_p * n)(*[srcs[i].data_ptr() for i in part])
+        dst_arr = (C.c_void_p * n)(*[outs[i].data_ptr() if n_keep else srcs[i].data_ptr() for i in part])
+        rb_arr = (C.c_int32 * n)(*[srcs[i][0].numel() * srcs[i].element_size() for i in part])
+        if n_keep:
+            _lib.check(lib.lg_compact_rows(N, dest.data_ptr(), n, src_arr, dst_arr, rb_arr, stream))
+    return outs
+
+
+def prune_points(model, mask):
+    """GaussianModel.prune_points(mask) (scene/gaussian_model.py:584-600) including the optimizer surgery of _prune_optimizer
+    (:564-582): the six parameters, both Adam moments of each and xyz_gradient_accum / denom / max_radii2D are compacted with
+    valid = ~mask in ONE compact_tensors call instead of 21 boolean-index kernels.  `model` is a reference GaussianModel (or
+    anything with the same attributes: optimizer with one named parameter per group, _xyz ... _rotation, the three
+    bookkeeping tensors).  Same state afterwards as the reference leaves, bit for bit (tests/test_gpu_compact.py)."""
+    from torch import nn
+    valid = ~mask.reshape(-1).bool()
+    opt = model.optimizer
+    plan, tensors = [], []
+    for group in opt.param_groups:
+        p = group["params"][0]
+        st = opt.state.get(p, None)
+        plan.append((group, p, st, len(tensors)))
+        tensors.append(p.data)
+        if st is not None:
+            tensors += [st["exp_avg"], st["exp_avg_sq"]]
+    extra0 = len(tensors)
+    tensors += [model.xyz_gradient_accum, model.denom, model.max_radii2D]
+    outs = compact_tensors(tensors, valid)
+    optimizable = {}
+    for group, p, st, i in plan:
+        if st is not None:
+            st["exp_avg"], st["exp_avg_sq"] = outs[i + 1], outs[i + 2]
+            del opt.state[p]
+            group["params"][0] = nn.Parameter(outs[i].requires_grad_(True))
+            opt.state[group["params"][0]] = st
+        else:
+            group["params"][0] = nn.Parameter(outs[i].requires_grad_(True))
+        optimizable[group["name"]] = group["params"][0]
+    model._xyz = optimizable["xyz"]
+    model._features_dc = optimizable["f_dc"]
+    model._features_rest = optimizable["f_rest"]
+    model._opacity = optimizable["opacity"]
+    model._scaling = optimizable["scaling"]
+    model._rotation = optimizable["rotation"]
+    model.xyz_gradient_accum, model.denom, model.max_radii2D = outs[extra0], outs[extra0 + 1], outs[extra0 + 2]
+    return optimizable
+
+
+def prune_gaussians(model, percent, import_score):
+    """GaussianModel.prune_gaussians (scene/gaussian_model.py:776-782): threshold by one radix select, then prune_points."""
+    score = import_score.reshape(-1)
+    if score.is_cuda:
+        _, mask = _select_mask(score.detach().contiguous().float(), int(percent * (score.shape[0] - 1)))
+        mask = mask.bool()
+    else:
+        mask = prune_mask(percent, import_score)
+    prune_points(model, mask)
+    return mask

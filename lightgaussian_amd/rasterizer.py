@@ -13,6 +13,8 @@ All arithmetic runs in liblightgaussian_hip.so (hand-written gfx950 kernels) thr
 include/lightgaussian.h; torch supplies device memory, the current stream and autograd plumbing.
 """
 import ctypes as C
+import os
+import threading
 from typing import NamedTuple
 
 import torch
@@ -39,7 +41,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # process-wide knobs that are not part of the reference API
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
-            "fuse_getters": True}
+            "fuse_getters": True, "sync_free": False, "max_depth": 100.0, "capacity_margin": 1.25}
 
 
 def set_option(name, value):
@@ -50,7 +52,13 @@ def set_option(name, value):
     fuse_getters (default True): gaussian_renderer.render() evaluates the getters of a reference GaussianModel inside the
               kernels (LG_FLAG_RAW_PARAMS) instead of in torch; False = the reference's literal getter pattern;
     skip_color_in_count: count renders do not evaluate colours and do not write the image (the returned `render` tensor is
-              uninitialised memory); for passes that only consume gaussians_count / important_score, e.g. prune_list_sharded."""
+              uninitialised memory); for passes that only consume gaussians_count / important_score, e.g. prune_list_sharded;
+    sync_free (default False): forwards go through lg_forward_bounded -- no blocking read of the instance count, so one host
+              thread can keep several views in flight on several streams.  The binning buffer is sized capacity_margin x the
+              largest instance count seen so far for this (N, W, H) (the first view of a shape takes the exact path to learn it)
+              and depths are laid out for max_depth (the camera's zfar; scene/cameras.py:64 uses 100).  A view that does not fit
+              is abandoned on the device; pending_overflow() (one sync for a whole batch of views) reports it and raises the
+              capacity, and the caller re-renders -- parallel.backward_over_views and the sharded prune pass do."""
     if name not in _OPTIONS:
         raise KeyError(name)
     _OPTIONS[name] = value
@@ -100,12 +108,118 @@ class _Call:
             flags |= _lib.FLAG_PROFILE
         if exact and _OPTIONS["skip_color_in_count"]:
             flags |= _lib.FLAG_SKIP_COLOR
+        # cross-check switches (tests toggle these environment variables at run time)
+        env = os.environ
+        if "LG_FORCE_PAIR_SORT" in env:
+            flags |= _lib.FLAG_PAIR_SORT
+        if "LG_SORT_ALL_BITS" in env:
+            flags |= _lib.FLAG_SORT_ALL_BITS
+        if "LG_K1_LDS" in env:
+            flags |= _lib.FLAG_K1_LDS
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
                                  int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags)
         self.g = _lib.lg_gaussians(N, M, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
                                    _ptr(self.scales), _ptr(self.rots), _ptr(self.cov), _ptr(self.sh_rest))
         self.N, self.M = N, M
+
+
+# ---- sync-free forwards: capacity bookkeeping --------------------------------------------------------------------------
+_CAP_LOCK = threading.Lock()
+_CAPACITY = {}      # (device index, N, W, H) -> binning capacity in instances
+_PENDING = []       # (status tensor [4] int32, key) of bounded forwards not yet checked
+
+
+def pending_status():
+    """Outcome of every sync-free forward issued since the last call, in issue order: a list of booleans, True = the view
+    was abandoned on the device (more instances than its binning capacity, or a depth beyond max_depth) and must be
+    re-rendered -- its image is the background, its counts / scores / gradients are zero.  ONE host sync for the whole batch.
+    The streams that issued the views must have been joined into the current stream.  Capacities are raised from the
+    instance counts the device reported, so the re-render (and later views of that shape) fit."""
+    with _CAP_LOCK:
+        pend = list(_PENDING)
+        _PENDING.clear()
+    if not pend:
+        return []
+    live = [p[0] for p in pend if p[0] is not None]
+    it = iter(torch.stack(live).cpu().tolist() if live else [])
+    out = []
+    for st, key in pend:
+        if st is None:                              # this forward took the exact path (first view of its shape)
+            out.append(False)
+            continue
+        flags, _viol, _dmax, R = next(it)
+        flags &= 0xFFFFFFFF
+        R &= 0xFFFFFFFF
+        out.append(flags != 0)
+        with _CAP_LOCK:
+            if flags & 2:
+                _CAPACITY.pop(key, None)           # depth bound violated: this shape goes back to the exact path
+            elif flags or key in _CAPACITY:
+                _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * _OPTIONS["capacity_margin"]) + 4096)
+    return out
+
+
+def pending_overflow():
+    """True when any sync-free forward since the last check was abandoned on the device (see pending_status)."""
+    return any(pending_status())
+
+
+def _note_count(key, R):
+    with _CAP_LOCK:
+        want = int(R * _OPTIONS["capacity_margin"]) + 4096
+        if want > _CAPACITY.get(key, 0):
+            _CAPACITY[key] = want
+
+
+def _native_forward(lib, call, rs, count):
+    """One forward through the C ABI.  Exact path (lg_forward / lg_forward_count: one blocking read of the instance count,
+    as the reference extension) or, with option sync_free and a known capacity for this shape, lg_forward_bounded.
+    Returns (color, radii, gcount, score, geom, binning, img, num_rendered)."""
+    dev, N = call.dev, call.N
+    H, W = int(rs.image_height), int(rs.image_width)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    geom = torch.empty(lib.lg_geom_bytes(N), **u8)
+    img = torch.empty(lib.lg_img_bytes(W, H), **u8)
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((N,), dtype=torch.int32, device=dev)
+    gcount = torch.empty((N,), dtype=torch.int32, device=dev) if count else None
+    score = torch.empty((N,), dtype=torch.float32, device=dev) if count else None
+    key = (dev.index, N, W, H)
+    cap = _CAPACITY.get(key) if (_OPTIONS["sync_free"] and N > 0 and not rs.prefiltered) else None
+    if cap is not None:
+        binning = torch.empty(lib.lg_binning_bytes(cap, W, H), **u8)
+        status = torch.empty(4, dtype=torch.int32, device=dev)
+        rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
+                                    float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
+                                    _ptr(gcount), _ptr(score), _ptr(status), stream)
+        _lib.check(rc)
+        with _CAP_LOCK:
+            _PENDING.append((status, key))
+        return color, radii, gcount, score, geom, binning, img, cap
+    holder = {}
+
+    def _alloc(_user, nbytes):
+        holder["t"] = torch.empty(max(int(nbytes), 1), **u8)
+        return holder["t"].data_ptr()
+
+    cb = _lib.ALLOC_FN(_alloc)
+    bin_ptr = C.c_void_p()
+    R = C.c_int64(0)
+    if count:
+        rc = lib.lg_forward_count(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None,
+                                  int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount), _ptr(score),
+                                  C.byref(bin_ptr), C.byref(R), stream)
+    else:
+        rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),
+                            C.byref(bin_ptr), C.byref(R), stream)
+    _lib.check(rc)
+    if _OPTIONS["sync_free"]:
+        _note_count(key, int(R.value))
+        with _CAP_LOCK:
+            _PENDING.append((None, key))           # keeps pending_status() aligned with the issue order
+    return color, radii, gcount, score, geom, holder.get("t"), img, int(R.value)
 
 
 def _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp):
@@ -124,37 +238,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         count = bool(rs.f_count)
         call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count)
-        dev, N = call.dev, call.N
-        H, W = int(rs.image_height), int(rs.image_width)
-        with torch.cuda.device(dev):
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            u8 = dict(dtype=torch.uint8, device=dev)
-            geom = torch.empty(lib.lg_geom_bytes(N), **u8)
-            img = torch.empty(lib.lg_img_bytes(W, H), **u8)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((N,), dtype=torch.int32, device=dev)
-            holder = {}
-
-            def _alloc(_user, nbytes):
-                holder["t"] = torch.empty(max(int(nbytes), 1), **u8)
-                return holder["t"].data_ptr()
-
-            cb = _lib.ALLOC_FN(_alloc)
-            bin_ptr = C.c_void_p()
-            R = C.c_int64(0)
-            if count:
-                gcount = torch.empty((N,), dtype=torch.int32, device=dev)
-                score = torch.empty((N,), dtype=torch.float32, device=dev)
-                rc = lib.lg_forward_count(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None,
-                                          int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount),
-                                          _ptr(score), C.byref(bin_ptr), C.byref(R), stream)
-            else:
-                rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color),
-                                    _ptr(radii), C.byref(bin_ptr), C.byref(R), stream)
-            _lib.check(rc)
-        binning = holder.get("t")
+        with torch.cuda.device(call.dev):
+            color, radii, gcount, score, geom, binning, img, num_rendered = _native_forward(lib, call, rs, count)
         ctx.raster_settings = rs
-        ctx.num_rendered = int(R.value)
+        ctx.num_rendered = num_rendered
         ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
                    scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
         ctx.save_for_backward(call.means3D, call.sh, call.colors, call.opac, call.scales, call.rots, call.cov, radii,
@@ -212,32 +299,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise Exception("raw-parameter rasterisation is a training path; use count_render for significance")
         rest = features_rest if (features_rest is not None and features_rest.shape[1] > 0) else None
         call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True)
-        dev, N = call.dev, call.N
-        H, W = int(rs.image_height), int(rs.image_width)
-        with torch.cuda.device(dev):
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            u8 = dict(dtype=torch.uint8, device=dev)
-            geom = torch.empty(lib.lg_geom_bytes(N), **u8)
-            img = torch.empty(lib.lg_img_bytes(W, H), **u8)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((N,), dtype=torch.int32, device=dev)
-            holder = {}
-
-            def _alloc(_user, nbytes):
-                holder["t"] = torch.empty(max(int(nbytes), 1), **u8)
-                return holder["t"].data_ptr()
-
-            cb = _lib.ALLOC_FN(_alloc)
-            bin_ptr = C.c_void_p()
-            R = C.c_int64(0)
-            rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),
-                                C.byref(bin_ptr), C.byref(R), stream)
-            _lib.check(rc)
+        with torch.cuda.device(call.dev):
+            color, radii, _gc, _sc, geom, binning, img, num_rendered = _native_forward(lib, call, rs, False)
         ctx.raster_settings = rs
-        ctx.num_rendered = int(R.value)
+        ctx.num_rendered = num_rendered
         ctx.has_rest = rest is not None
         ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
-        ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, holder.get("t"), img)
+        ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
 

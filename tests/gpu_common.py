@@ -48,3 +48,13 @@ def rel_err(a, b):
     """max |a-b| relative to max |b| (tensor-level relative error used for the 1e-4 contract)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def elem_excess(a, b, rtol=1e-4, atol_frac=2e-5):
+    """Element-wise check |a - b| <= rtol |b| + atol with atol = atol_frac * max|b| (an absolute floor for entries that are
+    small only through cancellation).  Returns (worst ratio |a-b| / bound, flat index of the worst element): <= 1 passes."""
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    bound = rtol * np.abs(b) + atol_frac * (np.abs(b).max() + 1e-300)
+    ratio = np.abs(a - b) / bound
+    i = int(ratio.argmax()) if ratio.size else 0
+    return (float(ratio[i]) if ratio.size else 0.0), i

@@ -1,0 +1,64 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` from a bare shell must become N ranks by itself
+(torch.distributed.run, rendezvous on 127.0.0.1), print ONE JSON line on rank 0 and verify that the prune mask does not
+depend on the rank count.  Driven here on CPU with --backend gloo --dry-run (tiny scene, synthetic per-view counter; the
+process group, the block-cyclic camera schedule, the ordered score exchange and the integer all-reduce are the real code
+of lightgaussian_amd.prune).  No GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                      # a bare shell: nothing of a distributed launch in the environment
+    e.update(env or {})
+    r = subprocess.run([sys.executable, BENCH, *argv], capture_output=True, text=True, env=e, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_self_launch_dry_run_prints_one_line_and_the_mask_equals_the_single_rank_mask(world):
+    r, recs = _run("--gpus", str(world), "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(recs) == 1, r.stdout
+    j = recs[0]
+    assert j["n_gpus"] == world and j["world_size_observed"] == world and j["dry_run"] is True
+    assert j["views"] == 5 * world
+    assert j["mask_equals_1gpu"] and j["counts_equal_1gpu"] and j["scores_bit_identical_1gpu"]
+    assert len(j["mask_sha256"]) == 64 and 0 < j["pruned"] < 4096
+
+
+def test_mask_digest_is_the_same_for_every_world_size():
+    digests = set()
+    for world, steps in ((1, 6), (2, 3), (3, 2)):          # the same 6-camera list, sharded 1 / 2 / 3 ways
+        r, recs = _run("--gpus", str(world), "--backend", "gloo", "--dry-run", "--steps", str(steps))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert recs[0]["views"] == 6
+        digests.add(recs[0]["mask_sha256"])
+    assert len(digests) == 1, digests
+
+
+def test_missing_devices_give_a_json_error_record_not_a_traceback():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    want = have + 8
+    r, recs = _run("--gpus", str(want), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert len(recs) == 1 and recs[0]["value"] is None and "error" in recs[0] and recs[0]["n_gpus"] == want
+    assert "Traceback" not in r.stderr
+    if have == 0:
+        r, recs = _run("--steps", "1", "--warmup", "0")     # N = 1 without any GPU: same treatment
+        assert r.returncode != 0 and recs and "error" in recs[0] and "Traceback" not in r.stderr
+
+
+def test_mismatched_world_size_is_refused():
+    r, recs = _run("--gpus", "2", "--backend", "gloo", "--dry-run", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and recs and "does not match" in recs[0]["error"]

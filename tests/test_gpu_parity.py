@@ -16,6 +16,10 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
+# scenes on which even the float32 ORACLE meets the element-wise bound |a-b| <= 1e-4|b| + 2e-5 max|b| against the float64 one
+# (measured on CPU: worst ratio 0.30 over all gradients; case 0 reaches 1.56 on scales/rotations, cases 1 and 7 8-1600):
+# there the HIP path must meet it too
+WELL_CONDITIONED = (2, 3, 4, 5, 6)
 TOL = 1e-4  # north_star tolerance for floating-point outputs (relative to tensor max)
 
 CASES = [
@@ -80,6 +84,14 @@ def test_backward_parity(case):
         floor = gpu_common.rel_err(g32[name], r)
         err = gpu_common.rel_err(g.reshape(r.shape), r)
         assert err <= max(TOL, 3.0 * floor), f"grad {name}: rel err {err:.3e} (fp32 oracle floor {floor:.3e})"
+        # element-wise: |a - b| <= 1e-4 |b| + 2e-5 max|b| on the well-conditioned scenes, where the float32
+        # oracle itself meets that bound; elsewhere within 3x of the float32 oracle's own worst element
+        ex, where = gpu_common.elem_excess(g.reshape(r.shape), r)
+        ex32, _ = gpu_common.elem_excess(g32[name], r)
+        assert ex <= max(1.0, 3.0 * ex32), (f"grad {name}: worst element {where} off by {ex:.2f}x the element-wise bound "
+                                            f"(fp32 oracle: {ex32:.2f}x); hip {g.reshape(-1)[where]:.6e} ref {r.reshape(-1)[where]:.6e}")
+        if CASES.index(case) in WELL_CONDITIONED:
+            assert ex32 <= 1.0 and ex <= 1.0, f"grad {name}: element-wise bound missed on a well-conditioned scene ({ex:.2f}x, fp32 oracle {ex32:.2f}x)"
 
 
 def test_render_equals_count_render_image():

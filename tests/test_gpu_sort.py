@@ -1,0 +1,65 @@
+"""-m gpu: K4 on its own (lg_debug_sort_keys: stand-alone histogram + hand-written onesweep passes) against torch's stable
+sort of the same bit field; the K2/K3 kernels are covered through the rasterizer's bit-exact parity tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from lightgaussian_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sort(keys, begin, end):
+    lib = _lib.load()
+    n = keys.shape[0]
+    out = torch.empty_like(keys)
+    temp = torch.empty(max(lib.lg_debug_sort_temp_bytes(n), 1), dtype=torch.uint8, device=keys.device)
+    _lib.check(lib.lg_debug_sort_keys(n, keys.data_ptr(), out.data_ptr(), begin, end, temp.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def _field(keys, begin, end):
+    return (keys >> begin) & ((1 << (end - begin)) - 1)
+
+
+@pytest.mark.parametrize("n,begin,end,seed", [(1, 0, 8, 0), (63, 3, 11, 1), (8192, 0, 32, 2), (8193, 22, 54, 3), (100_000, 22, 61, 4),
+                                              (1_000_003, 29, 61, 5), (4_141_089, 29, 61, 6), (300_000, 0, 5, 7), (70_000, 10, 23, 8)])
+def test_stable_sort_of_a_bit_field(n, begin, end, seed):
+    g = torch.Generator().manual_seed(seed)
+    keys = torch.randint(0, 2 ** 62, (n,), generator=g, dtype=torch.int64).to(DEV)
+    out = _sort(keys, begin, end)
+    f_in = _field(keys, begin, end)
+    order = torch.sort(f_in, stable=True).indices
+    assert torch.equal(out, keys[order]), "not the stable order of the sorted field"
+    assert torch.equal(keys, keys.clone())                          # input preserved (checked below against a copy)
+
+
+def test_skewed_digits_and_input_preserved():
+    g = torch.Generator().manual_seed(11)
+    n = 500_000
+    # tile-like top field with few distinct values, depth-like middle field, id in the low bits: the rasterizer's key shape
+    tile = torch.randint(0, 37, (n,), generator=g, dtype=torch.int64)
+    depth = (torch.rand(n, generator=g) ** 3 * (2 ** 19 - 1)).long()
+    keys = ((tile << 41) | (depth << 22) | torch.arange(n)).to(DEV)
+    copy = keys.clone()
+    out = _sort(keys, 22, 47)
+    assert torch.equal(keys, copy)
+    assert torch.equal(out, torch.sort(keys).values)               # ids unique and ascending => the stable order is the full order
+    # all keys equal in the sorted field: the sort must be the identity
+    same = (torch.full((n,), 5, dtype=torch.int64) << 30 | torch.arange(n)).to(DEV)
+    assert torch.equal(_sort(same, 30, 40), same)
+
+
+def test_back_to_back_sorts_on_one_stream_and_bad_arguments():
+    g = torch.Generator().manual_seed(12)
+    keys = torch.randint(0, 2 ** 40, (200_000,), generator=g, dtype=torch.int64).to(DEV)
+    a = _sort(keys, 0, 40)
+    b = _sort(a, 0, 40)
+    assert torch.equal(a, torch.sort(keys).values) and torch.equal(a, b)
+    lib = _lib.load()
+    assert lib.lg_debug_sort_keys(10, keys.data_ptr(), a.data_ptr(), 5, 5, keys.data_ptr(), None) == _lib.LG_ERR_INVALID_ARGUMENT
+    assert lib.lg_debug_sort_keys(0, None, None, 0, 8, None, None) == _lib.LG_OK

@@ -56,12 +56,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, block=24):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g, cams = _scene()
-        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), mode=mode, count_fn=oracle_count_fn)
+        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), mode=mode, count_fn=oracle_count_fn, block=block)
+        if rank == 0:   # local_only inside a distributed job = the single-process loop (what bench.py's mask_equals_1gpu recomputes)
+            c1, i1 = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn, local_only=True, block=3)
+            assert torch.equal(c1, cnt) and (mode != "ordered" or torch.equal(i1, imp))
         v = lg_prune.calculate_v_imp_score(g, imp, 0.1)
         mask = lg_prune.prune_mask(0.66, v)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), cnt=cnt.numpy(), imp=imp.numpy(), mask=mask.numpy())
@@ -69,12 +72,14 @@ def _worker(rank, world, port, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "ordered"), (3, "ordered"), (2, "allreduce")])
-def test_sharded_prune_pass_matches_single_process(world, mode, tmp_path):
+@pytest.mark.parametrize("world,mode,block", [(2, "ordered", 24), (3, "ordered", 2), (2, "ordered", 1), (2, "allreduce", 3)])
+def test_sharded_prune_pass_matches_single_process(world, mode, block, tmp_path):
+    """block = views per rank per round: 24 -> one round; 2 at world 3 -> rounds of 6 views with a ragged last round in which
+    two ranks own NO view (zero-length all_to_all splits); 1 -> seven rounds."""
     g, cams = _scene()
     cnt1, imp1 = lg_prune.prune_list(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn)
     mask1 = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, imp1, 0.1))
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), block), nprocs=world, join=True)
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     for o in outs:
         assert np.array_equal(o["cnt"], cnt1.numpy())                       # integer all-reduce: exact
@@ -85,6 +90,29 @@ def test_sharded_prune_pass_matches_single_process(world, mode, tmp_path):
         else:
             assert np.allclose(o["imp"], imp1.numpy(), rtol=1e-5)
             assert np.count_nonzero(o["mask"] != mask1.numpy()) <= 2
+
+
+def test_single_process_pass_in_bounded_chunks_equals_the_reference_loop():
+    """The running-sum form (scratch O(block * N)) adds the views in the reference's order: same bits for every
+    block size, including block > V and block = 1."""
+    g, cams = _scene()
+    cnt1, imp1 = lg_prune.prune_list(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn)
+    for block in (1, 3, 7, 50):
+        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn, block=block)
+        assert torch.equal(cnt, cnt1) and torch.equal(imp, imp1), block
+
+
+def test_round_schedule_covers_every_view_once_in_sequence_order():
+    for Vv in (1, 7, 200, 13):
+        for w in (1, 2, 3, 8):
+            for block in (1, 4, 24):
+                seen = []
+                for t in range(lg_prune.num_rounds(Vv, w, block)):
+                    for r in range(w):
+                        lo, hi = lg_prune.round_views(Vv, w, r, block, t)
+                        assert hi - lo <= block
+                        seen += list(range(lo, hi))
+                assert seen == list(range(Vv))
 
 
 def test_shard_bounds_partition():
