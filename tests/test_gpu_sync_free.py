@@ -1,0 +1,136 @@
+"""-m gpu: the capacity-bounded forward (lg_forward_bounded: no read-back of the instance count) against the exact forward.
+Same kernels, same total order of the tile lists => counts, scores, radii, image and gradients must be BIT-IDENTICAL; a view
+that does not fit its capacity (or exceeds the depth bound) must be reported on the device and contribute zeros."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from common import syn
+from lightgaussian_amd import rasterizer, prune, parallel
+from lightgaussian_amd.gaussian_renderer import render, count_render
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_options():
+    yield
+    rasterizer.set_option("sync_free", False)
+    rasterizer.set_option("max_depth", 100.0)
+    rasterizer.pending_status()
+    rasterizer._CAPACITY.clear()
+
+
+def _scene(N=20000, W=320, H=240, scale=0.03):
+    g = syn.make_gaussians(N, seed=5, log_scale_mean=math.log(scale)).to(DEV)
+    cams = [syn.orbit_camera(k, 6, W, H).to(DEV) for k in range(6)]
+    return g, cams, syn.PipelineParams(), torch.tensor([0.1, 0.2, 0.3], device=DEV)
+
+
+def test_bounded_forward_is_bit_identical_to_the_exact_forward():
+    g, cams, pipe, bg = _scene()
+    with torch.no_grad():
+        exact = [count_render(c, g, pipe, bg) for c in cams]
+        rasterizer.set_option("sync_free", True)
+        first = count_render(cams[0], g, pipe, bg)                 # learns the capacity on the exact path
+        assert rasterizer.pending_status() == [False]
+        free = [count_render(c, g, pipe, bg) for c in cams]        # all bounded now
+        flags = rasterizer.pending_status()
+    assert flags == [False] * len(cams)
+    for a, b in zip(exact, free):
+        for k in ("gaussians_count", "important_score", "radii", "render"):
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(first["gaussians_count"], exact[0]["gaussians_count"])
+
+
+def test_bounded_backward_is_bit_identical():
+    g, cams, pipe, bg = _scene(N=8000, W=200, H=120, scale=0.05)
+    gimg = torch.randn(3, 120, 200, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def grads():
+        pc = syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(True) for t in
+                                      (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)], 3, 3)
+        out = []
+        for c in cams[:3]:
+            for t in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity):
+                t.grad = None
+            pkg = render(c, pc, pipe, bg)
+            (pkg["render"] * gimg).sum().backward()
+            out.append([pkg["render"].detach().clone(), pkg["viewspace_points"].grad.clone()] +
+                       [t.grad.clone() for t in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)])
+        return out
+
+    a = grads()
+    rasterizer.set_option("sync_free", True)
+    render(cams[0], g, pipe, bg)                                    # exact, learns the capacity
+    b = grads()
+    assert rasterizer.pending_overflow() is False
+    for va, vb in zip(a, b):
+        for ta, tb in zip(va, vb):
+            assert torch.equal(ta, tb)
+
+
+def test_overflow_is_reported_on_the_device_and_the_view_contributes_zeros():
+    g, cams, pipe, bg = _scene()
+    with torch.no_grad():
+        ref = count_render(cams[1], g, pipe, bg)
+        rasterizer.set_option("sync_free", True)
+        key = (DEV.index, g.get_xyz.shape[0], 320, 240)
+        rasterizer._CAPACITY[key] = 1000                            # far too small
+        out = count_render(cams[1], g, pipe, bg)
+        assert rasterizer.pending_status() == [True]
+        assert int(out["gaussians_count"].sum()) == 0 and float(out["important_score"].abs().sum()) == 0.0
+        assert torch.equal(out["radii"], ref["radii"])             # K1 ran; only the binning was abandoned
+        assert rasterizer._CAPACITY[key] > 1000                     # raised from the count the device reported
+        again = count_render(cams[1], g, pipe, bg)
+        assert rasterizer.pending_status() == [False]
+        assert torch.equal(again["gaussians_count"], ref["gaussians_count"])
+        # a depth beyond max_depth: reported too, and the shape goes back to the exact path
+        rasterizer.set_option("max_depth", 1.0)
+        out = count_render(cams[1], g, pipe, bg)
+        assert rasterizer.pending_status() == [True] and key not in rasterizer._CAPACITY
+    # backward through an abandoned view: zero gradients, no out-of-bounds reads
+    rasterizer.set_option("max_depth", 100.0)
+    rasterizer._CAPACITY[key] = 1000
+    pc = syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(True) for t in
+                                  (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)], 3, 3)
+    pkg = render(cams[1], pc, pipe, bg)
+    pkg["render"].sum().backward()
+    assert rasterizer.pending_status() == [True]
+    assert float(pc._xyz.grad.abs().sum()) == 0.0 and float(pc._features_rest.grad.abs().sum()) == 0.0
+
+
+def test_sharded_pass_single_thread_sync_free_equals_host_threads_and_the_plain_loop():
+    g, cams, pipe, bg = _scene(N=15000, W=256, H=160)
+    cams = cams * 3
+    with torch.no_grad():
+        c0, s0 = prune.prune_list(prune._FrozenGetters(g), list(cams), pipe, bg)
+        c1, s1 = prune.prune_list_sharded(g, list(cams), pipe, bg, streams=3, block=5)
+        c2, s2 = prune.prune_list_sharded(g, list(cams), pipe, bg, streams=3, block=5, host_threads=True)
+        # capacity too small for every view: each block is repaired on the exact path
+        rasterizer._CAPACITY[(DEV.index, 15000, 256, 160)] = 64
+        c3, s3 = prune.prune_list_sharded(g, list(cams), pipe, bg, streams=3, block=4)
+    for c, s in ((c1, s1), (c2, s2), (c3, s3)):
+        assert torch.equal(c, c0) and torch.equal(s, s0)
+
+
+def test_backward_over_views_single_thread_equals_host_threads():
+    g, cams, pipe, bg = _scene(N=6000, W=160, H=96, scale=0.05)
+    targets = [torch.rand(3, 96, 160, device=DEV) for _ in cams]
+    loss_fn = lambda img, gt: (img - gt).abs().mean()  # noqa: E731
+
+    def run(**kw):
+        pc = syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(True) for t in
+                                      (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)], 3, 3)
+        losses = parallel.backward_over_views(pc, cams, targets, pipe, bg, loss_fn, streams=3, **kw)
+        return [float(x) for x in losses], [t.grad.clone() for t in (pc._xyz, pc._features_rest, pc._scaling, pc._opacity)]
+
+    la, ga = run(host_threads=True)
+    lb, gb = run()
+    assert la == lb
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
