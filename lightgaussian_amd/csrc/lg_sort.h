@@ -176,7 +176,12 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
         if (tile > 0) {
             for (int64_t b = (int64_t)tile - 1; b >= 0; b--) {
                 uint32_t s = lg_ld_state(&states[(size_t)b * 256 + tid]);
-                while ((s >> 30) == 0u) { __builtin_amdgcn_s_sleep(1); s = lg_ld_state(&states[(size_t)b * 256 + tid]); }
+                // (bounded spin: a predecessor always publishes -- ticket order -- so the bound is never reached; it turns a
+                // would-be hang of the device into a wrong result that the tests catch)
+                for (uint32_t spin = 0; (s >> 30) == 0u && spin < (1u << 22); spin++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    s = lg_ld_state(&states[(size_t)b * 256 + tid]);
+                }
                 excl += s & LG_SORT_VALUE_MASK;
                 if ((s >> 30) == LG_SORT_FLAG_PREFIX) break;
             }
