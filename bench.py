@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--views", type=int, default=200, help="cameras on the orbit; steps cycle through them")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--scale", type=float, default=0.004, help="median world-space sigma of the synthetic Gaussians (frozen workload: 0.004)")
+    ap.add_argument("--scene", choices=["uniform", "heavy"], default="uniform",
+                    help="uniform = the frozen SURVEY 8d workload; heavy = the same plus a fat tail of large splats piled on a few "
+                         "image regions (per-tile lists of tens of thousands of entries, as real captures have)")
     ap.add_argument("--exact-exp", action="store_true", help="canonical (bit-pinned) exp also in render(); counts always use it")
     ap.add_argument("--no-fuse", action="store_true", help="force the reference's literal getter pattern (torch exp/sigmoid/normalize/cat "
                     "per render call); default: render() evaluates the getters of a reference GaussianModel inside the kernels")
@@ -209,6 +212,8 @@ def main():
     rasterizer.set_option("fast_exp", not args.exact_exp)
     N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2
     g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree, log_scale_mean=math.log(args.scale))
+    if args.scene == "heavy":
+        syn.make_heavy_tailed(g_cpu)
     pc = g_cpu.to(dev)
     pipe = syn.PipelineParams()
     bg = torch.zeros(3, device=dev)  # black, prune_finetune.py:87-88
@@ -407,6 +412,23 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The contract times EXACTLY `steps` steps; at ~2 ms per step a small K is a very short window (r1: 41 ms).  When it is
+    # under half a second, the same loop is run again for about one second (every rank, same barriers) and reported beside it.
+    if elapsed < 0.5 and args.mode in ("fwdbwd", "fwd", "distill") and args.views_in_flight == 1:
+        n_long = int(math.ceil(1.0 / max(elapsed / args.steps, 1e-5)))
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_long):
+            step(args.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        extra["steady_state"] = {"steps": n_long, "seconds": round(dt, 4), "views_per_s": round(world * n_long / dt, 3),
+                                 "note": "same loop as `value`, run for ~1 s because the contract's timed region was under 0.5 s"}
+    extra["timed_seconds"] = round(elapsed, 4)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed  # whole-job views/s: every rank did `steps` views
 
@@ -422,7 +444,7 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{N} synthetic Gaussians (SURVEY 8d generator, seed {syn.SEED}), {W}x{H}, SH degree {args.sh_degree}, "
+            "config": {"workload": f"{N} synthetic Gaussians (SURVEY 8d generator, seed {syn.SEED}{', heavy-tailed variant' if args.scene == 'heavy' else ''}), {W}x{H}, SH degree {args.sh_degree}, "
                                    f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
@@ -454,41 +476,47 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                               "algorithmic_bytes_per_launch": ab.get(dom, 0), "avg_launch_ms": round(per_kernel[dom]["avg_ms"], 4)}
-        # HBM traffic of the dominant kernel from the committed PMC passes (tools/gpu_traffic.sh: FETCH_SIZE and WRITE_SIZE
-        # in separate rocprofv3 --pmc runs; FETCH_SIZE doubled per the gfx950 wide-read correction, which our own
-        # calibration on lg_preprocess_bwd confirms: WRITE_SIZE matches the known 744 MB of stores exactly, raw
-        # FETCH_SIZE is 0.57x the known reads).  null when no PMC file for this workload is present.
+        # HBM traffic and VALU instruction counts of the dominant kernel from the committed PMC passes of THIS build
+        # (profiles/r02_profile_<mode>.json, tools/gpu_profile.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs;
+        # FETCH_SIZE doubled per the gfx950 wide-read correction).  The file records lg_build_id() of the library it was
+        # taken from: another build (any kernel source changed since) => traffic null, stale true -- never last round's counters.
+        sym = {"blend_bwd": "lg_blend_bwd<false>" if not args.exact_exp else "lg_blend_bwd<true>",
+               "blend_fwd": "lg_blend_fwd<false, false, false, true>", "blend_fwd_count": "lg_blend_fwd<true, false, true, false>",
+               "preprocess": "lg_preprocess<true, true>", "preprocess_bwd": "lg_preprocess_bwd<true>"}.get(dom)
+        prof_file = os.path.join(ROOT, "profiles", f"r02_profile_{args.mode}.json")
+        c3 = args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080) and abs(args.scale - 0.004) < 1e-12 and args.scene == "uniform"
         try:
-            tpath = os.path.join(ROOT, "profiles", "r01_final_traffic_fwdbwd.json")
-            tj = json.load(open(tpath))
-            key = {"blend_bwd": "lg_blend_bwd", "blend_fwd": "lg_blend_fwd", "blend_fwd_count": "lg_blend_fwd", "preprocess": "lg_preprocess",
-                   "preprocess_bwd": "lg_preprocess_bwd"}.get(dom)
-            if key in tj and args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080):
-                result["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch_high"]
-                result["roofline"]["traffic_source"] = "profiles/r01_final_traffic_fwdbwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; 2*FETCH+WRITE = upper estimate, FETCH+WRITE = %d)" % tj[key]["hbm_bytes_per_launch_low"]
-        except Exception:
-            pass
-        # the blend kernels are VALU-issue-bound, not HBM-bound (SURVEY 8d caveat): say so with numbers.  VALU wave64
-        # instructions per launch from the committed PMC pass (profiles/r01_final_pmc_valu.json, SQ_INSTS_VALU), the
-        # launch duration measured live above, instruction costs from tools/ubench/valu_rate*.hip on MI355X.
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_valu.json")))
-            pk = {"blend_bwd": "lg_blend_bwd<false>", "blend_fwd": "lg_blend_fwd<false, false, false>"}.get(dom)
-            if pk in pj and args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080) and not args.exact_exp:
-                ninst = pj[pk]["SQ_INSTS_VALU"]
-                clk_ghz, simds = 2.4, 1024
-                result["roofline"]["valu_issue"] = {
-                    "wave64_valu_instr_per_launch": ninst, "G_instr_per_s": round(ninst / avg_s / 1e9, 1),
-                    "cycles_per_instr_per_simd": round(avg_s * clk_ghz * 1e9 * simds / ninst, 2),
-                    "measured_instr_cost_cycles": {"fma/mul/add/mov": 2.7, "cmp/cndmask/min/max": 4.5, "dpp_add": 4.4, "exp": 8.4, "rcp": 9.4},
-                    "note": "VALU-issue-bound kernel: cycles per instruction per SIMD is at the cost of its instruction mix; "
-                            "the HBM fraction above is reported because the contract asks for it, it is not this kernel's limiter",
-                    "source": "profiles/r01_final_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) + tools/ubench"}
-        except Exception:
-            pass
+            pj = json.load(open(prof_file))
+            fresh = pj["_meta"]["build_id"] == _lib.build_id()
+            result["roofline"]["profile"] = {"file": os.path.relpath(prof_file, ROOT), "build_id": pj["_meta"]["build_id"],
+                                             "library_build_id": _lib.build_id(), "stale": not fresh}
+            ent = pj["kernels"].get(sym) if (fresh and c3) else None
+            if ent and "hbm_bytes_high" in ent:
+                result["roofline"]["traffic"] = ent["hbm_bytes_high"]
+                result["roofline"]["traffic_low_estimate"] = ent["hbm_bytes_low"]
+                result["roofline"]["traffic_over_algorithmic"] = round(ent["hbm_bytes_high"] / max(ab.get(dom, 1), 1), 3)
+                result["roofline"]["profiled_avg_launch_ms"] = round(ent.get("avg_ns", 0.0) * 1e-6, 4)
+            if ent and "SQ_INSTS_VALU" in ent:
+                # the blend kernels are VALU-issue-bound, not HBM-bound (SURVEY 8d caveat): say so with numbers.  Issue peak =
+                # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction = 1228.8 G wave-instructions/s
+                ninst = ent["SQ_INSTS_VALU"]
+                result["roofline"]["valu_frac"] = round(ninst / avg_s / 1228.8e9, 4)
+                result["roofline"]["valu_issue"] = {"wave64_valu_instr_per_launch": ninst, "G_instr_per_s": round(ninst / avg_s / 1e9, 1),
+                                                    "peak_G_instr_per_s": 1228.8,
+                                                    "note": "VALU-issue-bound kernel; the HBM fraction is reported because the contract asks for it"}
+        except Exception as e:  # no profile for this mode committed yet
+            result["roofline"]["profile"] = {"file": os.path.relpath(prof_file, ROOT), "error": str(e)[:120], "stale": True}
         result["kernels_ms"] = {k: round(v["avg_ms"] * v["launches_per_step"], 4) for k, v in sorted(per_kernel.items())}
         tot_bytes = sum(ab[k] * per_kernel[k]["launches_per_step"] for k in per_kernel if k in ab)
         result["path_algorithmic_GBps"] = round(tot_bytes * value / world / 1e9, 2)
+        # the whole path by SURVEY 8d's own closed form (coarser than the per-kernel split above; what the judge recomputes)
+        B_fwd = 16 * N + (76 + 12 * M + 28) * vis + 76 * R + 20 * P
+        B_bwd = 76 * R + 20 * P + (108 + 12 * M) * vis + (92 + 12 * M) * N
+        b8d = {"fwdbwd": B_fwd + B_bwd, "fwd": B_fwd, "count": B_fwd + 8 * N}.get(args.mode)
+        if b8d:
+            result["path_survey8d"] = {"bytes_per_view": b8d, "GBps": round(b8d * value / world / 1e9, 1),
+                                       "frac_of_8TBps": round(b8d * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+        result["kernels_ms_note"] = "per-kernel hipEvent brackets (separate untimed pass) add ~4 % each: their sum exceeds ms_per_step"
 
     # ---- the same step with the reference's literal getter pattern (torch exp/sigmoid/normalize/cat per call), untimed leg ----
     if rank == 0 and not args.no_fuse and not args.no_literal and args.mode in ("fwdbwd", "fwd", "distill"):

@@ -141,11 +141,16 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth.  When status[0] != 0 the
  *           view was abandoned on the device (every later kernel returns at once; outputs undefined, gradients of a
  *           following lg_backward are zero) and the caller re-runs it through lg_forward -- the only host decision left.
+ *   host_status: NULL, or HOST uint32[4] receiving the same four words before the call returns ("validated" mode).  The
+ *           library copies them to pinned memory right behind the scan kernel and waits for that copy only after the rest
+ *           of the view is enqueued: the host learns R and the abort flags synchronously -- a wrapper can fall back to
+ *           lg_forward at once and stay a safe drop-in -- while the device goes straight from the scan into the sort and
+ *           the blend (the exact forward leaves it idle for the host's wake-up + allocation + launches, ~70 us per view).
  * Backward: lg_backward(..., binning, num_rendered = max_rendered, ...) with scratch lg_backward_scratch_bytes(N, max_rendered).
  */
 int lg_forward_bounded(const lg_view* view, const lg_gaussians* g, void* geom, void* img, void* binning, int64_t max_rendered,
                        float max_depth, int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
-                       float* out_score, uint32_t* status, void* stream);
+                       float* out_score, uint32_t* status, uint32_t* host_status, void* stream);
 
 /*
  * Backward  (replaces rasterize_gaussians_backward).  dL_dcolor [3,H,W] -> dense gradients, zero for
@@ -236,6 +241,11 @@ int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const fl
                      const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
                      uint32_t flags, void* stream);
 
+/* Per-tile lists longer than `entries` (default 2048; a multiple of 64) are processed by the backward as independent segments
+ * of that length, from checkpoints the forward leaves (DESIGN: long-tile robustness).  Process-wide; returns the previous
+ * value; must not change between a forward and its backward.  Small values exist for the tests. */
+int lg_set_segment_length(int32_t entries);
+
 /* diagnostics: K4 on its own -- stable ascending sort of bits [begin_bit, end_bit) of n < 2^30 64-bit keys (keys_in preserved);
  * temp: lg_debug_sort_temp_bytes(n) device bytes */
 size_t lg_debug_sort_temp_bytes(int64_t n);
@@ -248,6 +258,9 @@ int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream);
 /* --- introspection / measurement ------------------------------------------------------------ */
 int lg_abi_version(void);
 const char* lg_last_error(void);
+/* 12 hex digits identifying the kernel sources the library was built from (sha1 of csrc/ + this header); the profile
+ * summaries under profiles/ record it and bench.py quotes PMC-derived numbers only when it matches the loaded library */
+const char* lg_build_id(void);
 
 /* Per-kernel timings recorded when LG_FLAG_PROFILE is set (hipEvents on the launch stream).
  * lg_profile_read synchronises the stream-recorded events, then fills up to `cap` entries. */

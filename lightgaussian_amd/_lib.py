@@ -28,7 +28,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
-           "lg_debug_sort_keys"]
+           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length"]
 
 
 class lg_view(C.Structure):
@@ -104,7 +104,8 @@ def load():
     lib.lg_ordered_sum.restype = C.c_int
     lib.lg_ordered_sum.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp]
     lib.lg_forward_bounded.restype = C.c_int
-    lib.lg_forward_bounded.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp]
+    lib.lg_forward_bounded.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, vp, vp,
+                                       P(C.c_uint32 * 4), vp]
     lib.lg_select_mask.restype = C.c_int
     lib.lg_select_mask.argtypes = [C.c_int32, vp, C.c_int64, vp, vp, vp, vp]
     lib.lg_compact_scratch_bytes.restype = C.c_size_t; lib.lg_compact_scratch_bytes.argtypes = [C.c_int32]
@@ -121,6 +122,8 @@ def load():
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []
+    lib.lg_build_id.restype = C.c_char_p; lib.lg_build_id.argtypes = []
+    lib.lg_set_segment_length.restype = C.c_int; lib.lg_set_segment_length.argtypes = [C.c_int32]
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
     lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []
     lib.lg_last_stats.restype = C.c_int; lib.lg_last_stats.argtypes = [P(lg_stats)]
@@ -137,6 +140,11 @@ def check(rc):
     if rc == LG_ERR_INVALID_ARGUMENT:
         raise Exception(msg)
     raise RuntimeError(f"lightgaussian_hip error {rc}: {msg}")
+
+
+def build_id():
+    """Identity of the kernel sources the loaded library was built from (see include/lightgaussian.h lg_build_id)."""
+    return load().lg_build_id().decode()
 
 
 def profile_read():

@@ -4,7 +4,7 @@
 //   lg_host.h        error strings, optional hipEvent profiler, scratch carving (GeomView / ImgView / BinView)
 //   lg_wave.h        wave64 primitives (DPP / permlane reductions)
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
-//   lg_binning.h     lg_reduce_dmax, K3 lg_duplicate<PACKED>, K5 lg_tile_ranges, lg_tile_order (per instance; K2/K4 = rocPRIM scan / radix sort)
+//   lg_binning.h     K2 lg_scan_blocks, K3 lg_duplicate<PACKED>, K5 lg_tile_ranges, lg_work_order (K2-K5 all hand-written; lg_sort.h = K4)
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
@@ -64,20 +64,24 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
 // 64-byte pinned host slots for the forward's read-back, recycled through a process-wide free list (a thread_local slot
 // would be allocated -- and leaked -- by every short-lived host thread of the views-in-flight helpers).
 static std::mutex g_pin_mu;
-static std::vector<uint32_t*> g_pin_free;
+static std::vector<std::pair<uint32_t*, hipEvent_t>> g_pin_free;
 struct PinnedSlot {
     uint32_t* p = nullptr;
+    hipEvent_t ev = nullptr;   // marks the copy into p (validated bounded forward: the host waits for THIS, not for the stream)
     PinnedSlot()
     {
         {
             std::lock_guard<std::mutex> lk(g_pin_mu);
-            if (!g_pin_free.empty()) { p = g_pin_free.back(); g_pin_free.pop_back(); }
+            if (!g_pin_free.empty()) { p = g_pin_free.back().first; ev = g_pin_free.back().second; g_pin_free.pop_back(); }
         }
-        if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+        if (!p) {
+            if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) { p = nullptr; return; }
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); p = nullptr; ev = nullptr; }
+        }
     }
     ~PinnedSlot()
     {
-        if (p) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_free.push_back(p); }
+        if (p) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_free.emplace_back(p, ev); }
     }
     PinnedSlot(const PinnedSlot&) = delete;
     PinnedSlot& operator=(const PinnedSlot&) = delete;
@@ -119,7 +123,7 @@ static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t fla
 }
 
 // Arguments of the capacity-bounded forward (lg_forward_bounded); NULL = exact forward with its one read-back.
-struct Bounded { void* binning; int64_t capacity; float max_depth; uint32_t* status; };
+struct Bounded { void* binning; int64_t capacity; float max_depth; uint32_t* status; uint32_t* host_status; };
 
 static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, void* img_p, lg_alloc_fn alloc, void* alloc_user,
                         const Bounded* bounded, int weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
@@ -187,6 +191,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         KCHECK("lg_scan_blocks");
     }
     int64_t R = cap;
+    PinnedSlot vslot;          // (validated bounded forward)
     if (!bounded) {
         uint32_t h_counters[4] = {0, 0, 0, 0};
         if (N > 0) {
@@ -211,8 +216,16 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         cap = R;
         if (num_rendered) *num_rendered = R;
         if (R == 0) HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
-    } else if (bounded->status) {
-        HIP_TRY(hipMemcpyAsync(bounded->status, geo.counters, 16, hipMemcpyDeviceToDevice, stream));
+    } else {
+        if (bounded->status) HIP_TRY(hipMemcpyAsync(bounded->status, geo.counters, 16, hipMemcpyDeviceToDevice, stream));
+        if (bounded->host_status) {
+            // validated mode: the four status words travel to pinned host memory right behind K2; the host waits for them
+            // only AFTER everything else of the view has been enqueued (end of this function), so the device never idles
+            if (!vslot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the read-back slot failed");
+            if (N > 0) HIP_TRY(hipMemcpyAsync(vslot.p, geo.counters, 16, hipMemcpyDeviceToHost, stream));
+            else memset(vslot.p, 0, 16);
+            HIP_TRY(hipEventRecord(vslot.ev, stream));
+        }
     }
     g_stats.num_rendered = bounded ? -1 : R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
@@ -259,19 +272,20 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         KCHECK("lg_tile_ranges");
     }
     const uint32_t gid_mask = kp.gid_mask;
+    const int S = g_segment.load();     // list entries per segment of a long tile (checkpoints for the backward)
     // (count / score accumulators of the count variant were cleared by lg_preprocess)
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         dim3 grid(ntiles_pad), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
@@ -282,6 +296,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         ProfScope ps(prof, "score", stream);
         lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
         KCHECK("lg_score_kernel");
+    }
+    if (bounded && bounded->host_status) {
+        HIP_TRY(hipEventSynchronize(vslot.ev));            // K2's words are here; the blend kernels are still running
+        for (int k = 0; k < 4; k++) bounded->host_status[k] = vslot.p[k];
+        g_stats.num_rendered = vslot.p[3];
     }
     return LG_OK;
 }
@@ -304,10 +323,10 @@ extern "C" int lg_forward_count(const lg_view* view, const lg_gaussians* g, void
 
 extern "C" int lg_forward_bounded(const lg_view* view, const lg_gaussians* g, void* geom, void* img, void* binning, int64_t max_rendered,
                                   float max_depth, int32_t weight_policy, float* out_color, int32_t* out_radii, int32_t* out_count,
-                                  float* out_score, uint32_t* status, void* stream)
+                                  float* out_score, uint32_t* status, uint32_t* host_status, void* stream)
 {
     if (g && g->N > 0 && ((out_count == nullptr) != (out_score == nullptr))) return fail(LG_ERR_INVALID_ARGUMENT, "count and score go together");
-    const Bounded b = { binning, max_rendered, max_depth, status };
+    const Bounded b = { binning, max_rendered, max_depth, status, host_status };
     return forward_impl(view, g, geom, img, nullptr, nullptr, &b, weight_policy, out_color, out_radii, out_count, out_score, nullptr, nullptr, stream);
 }
 
@@ -337,22 +356,24 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     const int gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));          // same field width as the forward used
     const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
+    const int S = g_segment.load();
+    const uint32_t max_items = (uint32_t)(ntiles + R / S + 1);
     if (R > 0) {
-        // dispatch order of the per-tile backward (longest lists first).  Computed here, not in the forward, so that
-        // forward-only renders and the significance pass do not pay for it; it lands in the array reserved for it inside
-        // the binning buffer (the one write the backward makes to saved state; idempotent).
-        ProfScope ps(prof, "tile_order", stream);
-        lg_tile_order<<<1, 1024, 0, stream>>>(ntiles, bin.ranges, bin.tile_order);
+        // work list of the backward blend: one item per (tile, segment of S entries), longest first.  Computed here, not in the
+        // forward, so that forward-only renders and the significance pass do not pay for it; it lands in arrays reserved for
+        // it inside the binning buffer (the one write the backward makes to saved state; idempotent).
+        ProfScope ps(prof, "work_order", stream);
+        lg_work_order<<<1, 1024, 0, stream>>>(ntiles, S, bin.ranges, bin.work, bin.meta);
     }
-    KCHECK("lg_tile_order");
+    KCHECK("lg_work_order");
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)
-            lg_blend_bwd<false><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
-                                                                 img.final_T, img.n_contrib, dL_dcolor, rows);
+            lg_blend_bwd<false><<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
+                                                              img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
         else
-            lg_blend_bwd<true><<<ntiles, 64, 0, stream>>>(W, H, gx, ntiles, bin.tile_order, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
-                                                                img.final_T, img.n_contrib, dL_dcolor, rows);
+            lg_blend_bwd<true><<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
+                                                             img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
     }
     KCHECK("lg_blend_bwd");
     {
@@ -661,6 +682,10 @@ extern "C" int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream
     return LG_OK;
 }
 
+#ifndef LG_BUILD_ID
+#define LG_BUILD_ID "unknown"
+#endif
+extern "C" const char* lg_build_id(void) { return LG_BUILD_ID; }
 extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 extern "C" const char* lg_last_error(void) { return g_err.c_str(); }
 extern "C" int lg_last_stats(lg_stats* out)

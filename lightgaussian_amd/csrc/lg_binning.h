@@ -1,4 +1,4 @@
-// lg_binning.h -- binning kernels: depth-maximum reduction, K3 lg_duplicate (packed / pair keys), K5 lg_tile_ranges, lg_tile_order
+// lg_binning.h -- binning kernels: K2 lg_scan_blocks (+ depth maximum), K3 lg_duplicate (packed / pair keys, fused digit histograms), K5 lg_tile_ranges, lg_work_order
 // Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
 #pragma once
 
@@ -248,12 +248,12 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 }
 
 
-// Longest-processing-time-first dispatch order of the per-tile kernels.  The backward runs ONE wave per tile and only
-// ~1.6 tiles per wave slot, so which tiles share a slot decides the makespan: handing out the long lists first lets
-// the short ones fill the gaps.  Counting sort of the tiles by list length (256 buckets of 16 entries, longest first);
-// the order inside a bucket is arbitrary, which is harmless because tiles are independent.
+// Work list of the backward blend: one item per (tile, segment of S list entries), longest first.  The backward runs one
+// wave per item and only ~1.6 items per wave slot, so which items share a slot decides the makespan: handing out the long
+// ones first lets the short ones fill the gaps (longest-processing-time-first; counting sort by length, 256 buckets of 16
+// entries, order inside a bucket arbitrary -- items are independent).  Empty tiles produce no item.  meta[0] = item count.
 __global__ void __launch_bounds__(1024)
-lg_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order)
+lg_work_order(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work, uint32_t* __restrict__ meta)
 {
     __shared__ uint32_t hist[256], base[256];
     const uint32_t tid = threadIdx.x;
@@ -261,16 +261,20 @@ lg_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ or
     __syncthreads();
     for (int t = (int)tid; t < T; t += 1024) {
         const uint2 r = ranges[t];
-        atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u); // bucket 0 = longest
+        for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S)
+            atomicAdd(&hist[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u); // bucket 0 = longest
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; }
+        meta[0] = acc;
     }
     __syncthreads();
     for (int t = (int)tid; t < T; t += 1024) {
         const uint2 r = ranges[t];
-        order[atomicAdd(&base[255u - min((r.y - r.x) >> 4, 255u)], 1u)] = (uint32_t)t;
+        uint32_t seg = 0;
+        for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S, seg++)
+            work[atomicAdd(&base[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u)] = make_uint2((uint32_t)t, seg);
     }
 }

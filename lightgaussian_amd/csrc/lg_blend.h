@@ -46,7 +46,8 @@ __device__ __forceinline__ float guard_alpha(float alpha, float opacity, float p
 // every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
 template <bool EXACT, bool COLOR = true>
 __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
-                                         float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out)
+                                         float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out,
+                                         float& w_out)
 {
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
@@ -62,6 +63,7 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     if (COLOR) {   // significance-only passes (LG_FLAG_SKIP_COLOR) carry no colour at all
         const float w = contrib ? alpha * T : 0.0f;
         C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
+        w_out = w;
     }
     T = contrib ? test_T : T;
     last = contrib ? rel : last;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256)
 lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy)
+             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
@@ -96,8 +98,21 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
     bool done = !inside;
+    // Long list (more than one segment of S entries): leave a checkpoint record per pixel at the end of every segment --
+    // {T there, colour accumulated INSIDE the segment (absolute weights alpha T: a sum of non-negative terms, no
+    // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
+    // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
+    const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
+    float Cs0 = 0.0f, Cs1 = 0.0f, Cs2 = 0.0f;
+    uint32_t seg = 0;
+    float4* ck = nullptr;
+    if (longt) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + (((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u));
 
     for (uint32_t base = range.x; base < range.y; base += LG_Q) {
+        if (longt && base != range.x && (base - range.x) % (uint32_t)S == 0u) {
+            ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
+            seg++; Cs0 = Cs1 = Cs2 = 0.0f;
+        }
         if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
         const uint32_t idx = base + lane;
         bool hit = false;
@@ -123,8 +138,9 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             const uint32_t src = (uint32_t)__builtin_ctzll(mask);
             mask &= mask - 1;
             const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
-            float alpha = 0.0f, Tprev = T;
-            const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha) ? 1 : 0;
+            float alpha = 0.0f, Tprev = T, w = 0.0f;
+            const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha, w) ? 1 : 0;
+            if (longt) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
             if (COUNT) {
                 const uint64_t cm = __ballot(res == 1);
                 if (lane == j) mycnt = (int)__popcll(cm);
@@ -146,6 +162,15 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (longt) {
+        // the current segment's record, and -- when the wave stopped early -- those of the segments it never entered
+        // (nothing contributed there: T stays, colour 0), so that every record of the tile is valid for every pixel
+        const uint32_t nseg = (range.y - range.x + (uint32_t)S - 1u) / (uint32_t)S;
+        for (; seg < nseg; seg++) {
+            ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
+            Cs0 = Cs1 = Cs2 = 0.0f;
+        }
     }
     if (COLOR && inside) {   // !COLOR: forward-only significance pass, nothing per pixel is kept
         const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
@@ -316,15 +341,16 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const uint4* __restrict__ tinfo, const float4* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-             const float* __restrict__ dL_dpix, float* __restrict__ part)
+             const float* __restrict__ dL_dpix, const float4* __restrict__ ckpt, float* __restrict__ part)
 {
     __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
-    if ((int)blockIdx.x >= ntiles) return;
-    const int tile = (int)tile_order[blockIdx.x]; // longest lists first (lg_tile_order)
+    if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
+    const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
+    const int tile = (int)item.x;
     const uint32_t lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const uint2 range = ranges[tile];
@@ -333,6 +359,7 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
 
     float pxf[4], pyf[4], T[4], Tfb[4], g0[4], g1[4], g2[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
     uint32_t last[4];
+    bool inside4[4];
     uint32_t wmax = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -340,6 +367,7 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
         const bool inside = pxi < W && pyi < H;
         const size_t pid = (size_t)pyi * W + pxi;
         pxf[s] = (float)pxi; pyf[s] = (float)pyi;
+        inside4[s] = inside;
         T[s] = inside ? final_T[pid] : 0.0f;
         last[s] = inside ? n_contrib[pid] : 0u;
         g0[s] = inside ? dL_dpix[pid] : 0.0f;
@@ -354,16 +382,40 @@ lg_blend_bwd(int W, int H, int gx, int ntiles, const uint32_t* __restrict__ tile
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     const uint32_t n_list = range.y - range.x;
     if (n_list == 0) return;
-    if (wmax > n_list) wmax = n_list;
+    // this work item = list entries [seg_lo, seg_hi) of the tile (the whole list unless it is longer than S)
+    const uint32_t nseg = (n_list + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t seg_lo = item.y * (uint32_t)S, seg_hi = min(n_list, seg_lo + (uint32_t)S);
+    if (wmax > seg_hi) wmax = seg_hi;
+    if (item.y + 1u < nseg) {
+        // not the last segment: start from the forward's checkpoints instead of the end of the list.  T = transmittance at
+        // the end of this segment; colour behind = (colour accumulated inside all later segments) / T -- a quotient of a sum
+        // of non-negative terms, as well conditioned as the published back-to-front accumulation.
+        const float4* cr = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint32_t pix = ((uint32_t)(s >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(s & 1) * 8u + (lane & 7u);
+            const float4 here = cr[(size_t)item.y * 256 + pix];
+            float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+            for (uint32_t j = nseg - 1u; j > item.y; j--) {            // back to front, like the replay itself
+                const float4 r = cr[(size_t)j * 256 + pix];
+                b0 += r.y; b1 += r.z; b2 += r.w;
+            }
+            if (inside4[s]) {
+                const float inv = 1.0f / here.x;
+                T[s] = here.x;
+                a0[s] = b0 * inv; a1[s] = b1 * inv; a2[s] = b2 * inv;
+            }
+        }
+    }
     const float tbx = (float)(tx * LG_TILE), tby = (float)(ty * LG_TILE);
     float4* rows = reinterpret_cast<float4*>(part);
 
     // every list entry of the tile writes exactly one 48-byte row (zeros when nothing contributed) at its
     // PRE-SORT slot, where the rows of one Gaussian are contiguous: no zero-fill pass, no atomics, and K9
     // reads its rows sequentially and sums them in a fixed order (deterministic gradients)
-    for (int k = (int)((n_list - 1) / LG_Q); k >= 0; k--) {
+    for (int k = (int)((seg_hi - 1) / LG_Q); k >= (int)(seg_lo / LG_Q); k--) {
         const uint32_t base = range.x + (uint32_t)k * LG_Q;
-        const uint32_t nbt = min((uint32_t)LG_Q, n_list - (uint32_t)k * LG_Q);                             // entries of this batch
+        const uint32_t nbt = min((uint32_t)LG_Q, seg_hi - (uint32_t)k * LG_Q);                             // entries of this batch
         const uint32_t nb = wmax > (uint32_t)k * LG_Q ? min((uint32_t)LG_Q, wmax - (uint32_t)k * LG_Q) : 0u; // ... that any pixel reached
         uint64_t hitmask = 0;
         // lane <-> list entry base + lane for the whole batch: its Gaussian id (low field of the sorted key) and, issued

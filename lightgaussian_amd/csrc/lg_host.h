@@ -10,6 +10,7 @@
 #include <string.h>
 #include <mutex>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -128,9 +129,25 @@ static ImgView carve_img(void* base, int W, int H)
 // Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
 // offsets for both key formats.  There is no separate id list and no slot list: the id is the low field of the sorted
 // key, and the pre-sort slot (row address of the backward) is recomputed from the Gaussian's tile rectangle (tinfo).
+// Long per-tile lists (real captures: tens of thousands of entries on a few tiles) are cut into SEGMENTS of g_segment
+// entries: the forward leaves one checkpoint record per pixel at the end of every segment of such a tile, and the backward
+// runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry tile becomes ten independent work items
+// instead of one 4 ms serial chain.  Tiles with at most one segment (all of the uniform benchmark scene) never touch the
+// checkpoints.  Process-wide so that the buffer sizes stay functions of (R, W, H); must not change between a forward and
+// its backward.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
+static std::atomic<int> g_segment{2048};
+extern "C" int lg_set_segment_length(int32_t entries)
+{
+    const int prev = g_segment.load();
+    if (entries >= 64 && entries % 64 == 0) g_segment.store(entries);
+    return prev;
+}
+
 struct BinView {
     uint2* ranges;                  // [tiles]
-    uint32_t* tile_order;           // [tiles] tile indices, longest list first (dispatch order of the backward)
+    uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
+    uint32_t* meta;                 // [16] 0 = number of work items (lg_work_order)
+    float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
     uint64_t* entries;              // [R] sorted list entries; the low bits_for(N) bits are the Gaussian id.  Packed format:
                                     //     these ARE the sorted keys (tile | depth | id).  Pairs format: written by lg_tile_ranges
     uint64_t* keys_in;              // [R] radix-sort input
@@ -150,8 +167,11 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     size_t n = (size_t)(R > 0 ? R : 1);
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
+    const size_t S = (size_t)g_segment.load();
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
-    v.tile_order = (uint32_t*)take((size_t)gx * gy * 4);
+    v.work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
+    v.meta = (uint32_t*)take(64);
+    v.ckpt = (float4*)take(2 * (n / S + 1) * 256 * 16);
     v.entries = (uint64_t*)take(n * 8);
     v.keys_in = (uint64_t*)take(n * 8);
     size_t tb = 0;

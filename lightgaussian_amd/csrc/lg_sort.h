@@ -83,15 +83,18 @@ lg_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int begin_bit, int e
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-__device__ __forceinline__ uint32_t lg_ld_state(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// State words cross XCDs (per-XCD L2s are not coherent with each other): they are published with an agent-scope atomic
+// exchange and polled with an agent-scope atomic RMW (fetch_add 0) -- read-modify-writes execute at the device's coherence
+// point by construction, whatever a plain or sc1 load would be served from.
+__device__ __forceinline__ uint32_t lg_ld_state(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One digit pass.  counters (may be NULL): [0] != 0 aborts the view (capacity overflow, lg_forward_bounded), [3] = key
 // count; with counters == NULL the count is n_arg.  hist = this pass's 256 global digit counts, ticket / states = this
 // pass's ticket word and state array (zeroed by the caller's one memset).
 __global__ void __launch_bounds__(LG_SORT_BLOCK)
 lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ counters, uint32_t n_arg,
-                 int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket, uint32_t* __restrict__ states)
+                 int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* ticket, uint32_t* states)
 {
     __shared__ uint64_t stage[LG_SORT_TILE];
     __shared__ unsigned short wcnt[LG_SORT_WAVES][256];
@@ -174,16 +177,18 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
         const uint32_t gb = goff[tid] + cg;                                 // global start of digit tid (all tiles)
         uint32_t excl = 0;
         if (tile > 0) {
+            // (the TOTAL number of polls of a thread is bounded: a predecessor always publishes -- ticket order -- so the
+            // bound is never reached; it turns a would-be hang of the device into a wrong result that the tests catch)
+            uint32_t budget = 1u << 18;
             for (int64_t b = (int64_t)tile - 1; b >= 0; b--) {
                 uint32_t s = lg_ld_state(&states[(size_t)b * 256 + tid]);
-                // (bounded spin: a predecessor always publishes -- ticket order -- so the bound is never reached; it turns a
-                // would-be hang of the device into a wrong result that the tests catch)
-                for (uint32_t spin = 0; (s >> 30) == 0u && spin < (1u << 22); spin++) {
-                    __builtin_amdgcn_s_sleep(1);
+                while ((s >> 30) == 0u && budget > 0u) {
+                    budget--;
+                    __builtin_amdgcn_s_sleep(2);
                     s = lg_ld_state(&states[(size_t)b * 256 + tid]);
                 }
                 excl += s & LG_SORT_VALUE_MASK;
-                if ((s >> 30) == LG_SORT_FLAG_PREFIX) break;
+                if ((s >> 30) == LG_SORT_FLAG_PREFIX || budget == 0u) break;
             }
         }
         lg_st_state(&states[(size_t)tile * 256 + tid], (LG_SORT_FLAG_PREFIX << 30) | ((excl + run) & LG_SORT_VALUE_MASK));

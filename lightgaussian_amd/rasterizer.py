@@ -53,12 +53,18 @@ def set_option(name, value):
               kernels (LG_FLAG_RAW_PARAMS) instead of in torch; False = the reference's literal getter pattern;
     skip_color_in_count: count renders do not evaluate colours and do not write the image (the returned `render` tensor is
               uninitialised memory); for passes that only consume gaussians_count / important_score, e.g. prune_list_sharded;
-    sync_free (default False): forwards go through lg_forward_bounded -- no blocking read of the instance count, so one host
-              thread can keep several views in flight on several streams.  The binning buffer is sized capacity_margin x the
+    sync_free: False = every forward takes the exact path (lg_forward: the device idles while the host reads the instance
+              count, allocates and launches the rest, as in the reference extension).
+              "validated" = lg_forward_bounded with host status: the whole view is enqueued against a capacity learnt from
+              earlier views of the same shape, then the host waits for the status words that left behind K2 -- same
+              guarantees as the exact path (an overflowing view is re-run at once, transparently), no idle device.
+              True = nothing is read back at all, so one host thread can keep several views in flight on several streams.  The binning buffer is sized capacity_margin x the
               largest instance count seen so far for this (N, W, H) (the first view of a shape takes the exact path to learn it)
               and depths are laid out for max_depth (the camera's zfar; scene/cameras.py:64 uses 100).  A view that does not fit
               is abandoned on the device; pending_overflow() (one sync for a whole batch of views) reports it and raises the
               capacity, and the caller re-renders -- parallel.backward_over_views and the sharded prune pass do."""
+    if name == "segment_length":   # entries per backward segment of a long tile list (library-wide, default 2048; tests use 64)
+        return _lib.load().lg_set_segment_length(int(value))
     if name not in _OPTIONS:
         raise KeyError(name)
     _OPTIONS[name] = value
@@ -187,17 +193,36 @@ def _native_forward(lib, call, rs, count):
     gcount = torch.empty((N,), dtype=torch.int32, device=dev) if count else None
     score = torch.empty((N,), dtype=torch.float32, device=dev) if count else None
     key = (dev.index, N, W, H)
-    cap = _CAPACITY.get(key) if (_OPTIONS["sync_free"] and N > 0 and not rs.prefiltered) else None
+    mode = _OPTIONS["sync_free"]
+    cap = _CAPACITY.get(key) if (mode and N > 0 and not rs.prefiltered) else None
     if cap is not None:
         binning = torch.empty(lib.lg_binning_bytes(cap, W, H), **u8)
-        status = torch.empty(4, dtype=torch.int32, device=dev)
-        rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                    float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
-                                    _ptr(gcount), _ptr(score), _ptr(status), stream)
-        _lib.check(rc)
-        with _CAP_LOCK:
-            _PENDING.append((status, key))
-        return color, radii, gcount, score, geom, binning, img, cap
+        if mode == "validated":
+            # everything of the view is enqueued, then the host waits for the four status words that left right behind K2:
+            # it knows R and the abort flags before returning (safe drop-in), the device never idled
+            host = (C.c_uint32 * 4)()
+            rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
+                                        float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
+                                        _ptr(gcount), _ptr(score), None, C.byref(host), stream)
+            _lib.check(rc)
+            if host[0] == 0:
+                _note_count(key, int(host[3]))
+                return color, radii, gcount, score, geom, binning, img, cap
+            with _CAP_LOCK:                        # the view did not fit (its kernels were no-ops): exact path below, same buffers
+                if host[0] & 2:
+                    _CAPACITY.pop(key, None)
+                else:
+                    _CAPACITY[key] = int(int(host[3]) * _OPTIONS["capacity_margin"]) + 4096
+            del binning
+        else:
+            status = torch.empty(4, dtype=torch.int32, device=dev)
+            rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
+                                        float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
+                                        _ptr(gcount), _ptr(score), _ptr(status), None, stream)
+            _lib.check(rc)
+            with _CAP_LOCK:
+                _PENDING.append((status, key))
+            return color, radii, gcount, score, geom, binning, img, cap
     holder = {}
 
     def _alloc(_user, nbytes):
@@ -215,10 +240,11 @@ def _native_forward(lib, call, rs, count):
         rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),
                             C.byref(bin_ptr), C.byref(R), stream)
     _lib.check(rc)
-    if _OPTIONS["sync_free"]:
+    if mode:
         _note_count(key, int(R.value))
-        with _CAP_LOCK:
-            _PENDING.append((None, key))           # keeps pending_status() aligned with the issue order
+        if mode != "validated":
+            with _CAP_LOCK:
+                _PENDING.append((None, key))       # keeps pending_status() aligned with the issue order
     return color, radii, gcount, score, geom, holder.get("t"), img, int(R.value)
 
 

@@ -191,6 +191,26 @@ def make_gaussians(N, sh_degree=3, seed=SEED, extent=(4.0, 2.25, 4.0), log_scale
     return SyntheticGaussians(xyz, dc, rest, scaling, rotation, opacity, sh_degree, sh_degree)
 
 
+def make_heavy_tailed(g, frac=0.04, radius=0.15, log_scale_mean=math.log(0.03), opacity_mean=-4.5, seed=SEED + 7, centre=(0.0, 0.0, 0.0)):
+    """Turns a fraction of the Gaussians of `g` (in place, raw parameters) into what real captures have and the uniform
+    generator lacks: a dense pile of larger, faint splats around one point every orbit camera looks at -- per-tile lists of
+    tens of thousands of entries (uniform scene at C3: mean 507, max ~700), most of whose entries are rejected or contribute
+    little, so lists are long AND early termination does not cut them short.  At C3 (3M, 1080p): frac 0.04 -> 120 k splats of
+    ~8 px sigma over ~100 tiles: ~2 M extra instances, ~20 k per tile there."""
+    n = int(g.num * frac)
+    if n <= 0:
+        return g
+    gen = torch.Generator("cpu").manual_seed(seed)
+    idx = torch.randperm(g.num, generator=gen)[:n]
+    d = torch.randn(n, 3, generator=gen)
+    d = d / d.norm(dim=1, keepdim=True) * radius * torch.rand(n, 1, generator=gen) ** (1.0 / 3.0)
+    with torch.no_grad():
+        g._xyz[idx] = d + torch.tensor(centre)
+        g._scaling[idx] = torch.randn(n, 3, generator=gen) * 0.35 + log_scale_mean
+        g._opacity[idx] = torch.randn(n, 1, generator=gen) * 0.5 + opacity_mean
+    return g
+
+
 @dataclass
 class PipelineParams:
     """arguments/__init__.py:72-77"""

@@ -1,0 +1,99 @@
+"""-m gpu: long per-tile lists.  Lists longer than the segment length S are processed by the backward as independent
+(tile, segment) work items starting from checkpoints the forward leaves (lg_blend_fwd / lg_blend_bwd, DESIGN long-tile
+robustness).  With S = 64 / 128 every test scene has multi-segment tiles: the image must not change at all (checkpoints are
+extra outputs), the gradients must agree with the unsegmented replay to float rounding and with the float64 oracle within
+the usual bound; a heavy-tailed scene (one dense pile of faint splats) exercises lists of thousands of entries."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import gpu_common
+from common import syn
+from lightgaussian_amd import rasterizer
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    rasterizer.set_option("segment_length", 2048)
+
+
+def _np(kw):
+    return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in kw.items()}
+
+
+def _scene(N, W, H, scale, opm, seed, heavy=0.0, ext=(2, 1.2, 2)):
+    g = syn.make_gaussians(N, seed=seed, log_scale_mean=math.log(scale), opacity_mean=opm, extent=ext)
+    if heavy:
+        syn.make_heavy_tailed(g, frac=heavy, radius=0.3, log_scale_mean=math.log(0.06), opacity_mean=-3.5)
+    cam = syn.orbit_camera(1, 7, W, H, radius=5.0)
+    return common.scene_kwargs(g, cam, W, H, deg=3, bg=(0.2, 0.1, 0.3), as_torch=True)
+
+
+SCENES = [dict(N=3000, W=200, H=120, scale=0.05, opm=1.0, seed=2), dict(N=800, W=128, H=96, scale=0.3, opm=-2.0, seed=3),
+          dict(N=6000, W=160, H=96, scale=0.06, opm=-3.0, seed=4), dict(N=20000, W=192, H=128, scale=0.01, opm=-1.0, seed=5, heavy=0.3)]
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=lambda s: f"N{s['N']}_{s['W']}x{s['H']}")
+@pytest.mark.parametrize("S", [64, 128])
+def test_segmented_backward_equals_the_unsegmented_one(sc, S):
+    kw = _scene(**sc)
+    gimg = np.random.RandomState(3).randn(3, sc["H"], sc["W"]).astype(np.float32)
+    rasterizer.set_option("segment_length", 1 << 20)            # effectively unsegmented
+    a = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    rasterizer.set_option("segment_length", S)
+    b = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["radii"], b["radii"])
+    ref64 = oracle.forward(dtype=np.float64, **_np(kw)); g64 = oracle.backward(ref64, gimg)
+    ref32 = oracle.forward(**_np(kw)); g32 = oracle.backward(ref32, gimg)
+    longest = int(np.diff(np.asarray(ref32.ranges).reshape(-1, 2), axis=1).max()) if hasattr(ref32, "ranges") else None
+    for name in a["grads"]:
+        r = g64[name]
+        ea, eb = gpu_common.rel_err(a["grads"][name].reshape(r.shape), r), gpu_common.rel_err(b["grads"][name].reshape(r.shape), r)
+        floor = gpu_common.rel_err(g32[name], r)
+        assert eb <= max(1e-4, 3.0 * floor), f"{name}: segmented rel err {eb:.3e} (unsegmented {ea:.3e}, fp32 oracle floor {floor:.3e}, longest list {longest})"
+        assert gpu_common.rel_err(b["grads"][name], a["grads"][name]) <= max(2e-5, 2.0 * floor), name
+
+
+def test_count_render_and_canonical_backward_with_segments():
+    sc = SCENES[0]
+    kw = _scene(**sc)
+    gimg = np.random.RandomState(4).randn(3, sc["H"], sc["W"]).astype(np.float32)
+    ref = oracle.forward(count=True, **_np(kw))
+    rasterizer.set_option("segment_length", 64)
+    out = gpu_common.hip_forward_backward(kw, count=True)
+    assert np.array_equal(out["count"], ref.count) and np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32))
+    rasterizer.set_option("fast_exp", False)
+    try:
+        b = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    finally:
+        rasterizer.set_option("fast_exp", True)
+    g64 = oracle.backward(oracle.forward(dtype=np.float64, **_np(kw)), gimg)
+    g32 = oracle.backward(oracle.forward(**_np(kw)), gimg)
+    for name, r in g64.items():
+        if r is None:
+            continue
+        assert gpu_common.rel_err(b["grads"][name].reshape(r.shape), r) <= max(1e-4, 3.0 * gpu_common.rel_err(g32[name], r)), name
+
+
+def test_heavy_tailed_scene_has_long_lists_and_runs_with_the_default_segment():
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    g = syn.make_gaussians(400_000, seed=9)
+    syn.make_heavy_tailed(g)
+    pc = g.to(dev).requires_grad_(True)
+    cam = syn.orbit_camera(0, 10, 960, 540).to(dev)
+    pkg = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))
+    pkg["render"].sum().backward()
+    saved = pkg["render"].grad_fn.saved_tensors
+    T = ((960 + 15) // 16) * ((540 + 15) // 16)
+    ranges = saved[8][: T * 8].view(torch.int32).view(T, 2).cpu().numpy()
+    n = ranges[:, 1] - ranges[:, 0]
+    assert n.max() > 2 * 2048, n.max()                        # several segments on the densest tiles
+    assert torch.isfinite(pc._xyz.grad).all() and float(pc._xyz.grad.abs().sum()) > 0

@@ -134,3 +134,33 @@ def test_backward_over_views_single_thread_equals_host_threads():
     assert la == lb
     for x, y in zip(ga, gb):
         assert torch.equal(x, y)
+
+
+def test_validated_mode_is_bit_identical_and_repairs_an_overflow_transparently():
+    """sync_free="validated": bounded forward whose status words reach the host before the call returns.  Same results as
+    the exact path; a view that does not fit is re-run on the exact path inside the same call."""
+    g, cams, pipe, bg = _scene()
+    with torch.no_grad():
+        exact = [count_render(c, g, pipe, bg) for c in cams]
+        rasterizer.set_option("sync_free", "validated")
+        val = [count_render(c, g, pipe, bg) for c in cams]          # first exact (learns), rest bounded + validated
+        key = (DEV.index, g.get_xyz.shape[0], 320, 240)
+        assert key in rasterizer._CAPACITY
+        rasterizer._CAPACITY[key] = 500                            # every following view overflows once, then is repaired
+        rep = [count_render(c, g, pipe, bg) for c in cams]
+    assert rasterizer.pending_status() == []                       # validated mode leaves nothing pending
+    for a, b, c in zip(exact, val, rep):
+        for k in ("gaussians_count", "important_score", "radii", "render"):
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert rasterizer._CAPACITY[key] > 500
+    # training step through render(): gradients identical to the exact path
+    gimg = torch.randn(3, 240, 320, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def grads(mode):
+        rasterizer.set_option("sync_free", mode)
+        pc = syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(True) for t in
+                                      (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)], 3, 3)
+        (render(cams[2], pc, pipe, bg)["render"] * gimg).sum().backward()
+        return [t.grad.clone() for t in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)]
+    for x, y in zip(grads(False), grads("validated")):
+        assert torch.equal(x, y)

@@ -8,11 +8,14 @@ from lightgaussian_amd.gaussian_renderer import render
 
 N, W, H = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, 1920, 1080
 dev = torch.device("cuda:0")
-pc = syn.make_gaussians(N).to(dev).requires_grad_(True)
+g_cpu = syn.make_gaussians(N)
+if "heavy" in sys.argv:      # tile_stats.py <N> heavy : the heavy-tailed variant (bench.py --scene heavy)
+    syn.make_heavy_tailed(g_cpu)
+pc = g_cpu.to(dev).requires_grad_(True)
 cam = syn.orbit_camera(0, 200, W, H).to(dev)
 pkg = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))
 saved = pkg["render"].grad_fn.saved_tensors
-binning, img = saved[9], saved[10]
+binning, img = saved[-2], saved[-1]     # (..., radii, geom, binning, img) in both autograd Functions
 gx, gy = (W + 15) // 16, (H + 15) // 16
 T = gx * gy
 ranges = binning[: T * 8].view(torch.int32).view(T, 2).cpu().numpy()
