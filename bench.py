@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="fwdbwd/fwd: render this many independent views concurrently (host threads x HIP streams, gradients "
                          "accumulated per thread as in a camera batch > 1); 1 = the reference's one view per step")
+    ap.add_argument("--sync-free", choices=["default", "off", "validated"], default="default",
+                    help="rasterizer option sync_free for the timed loop: validated = bounded forward, status words read after the whole "
+                         "view is enqueued (no idle device at the read-back of R); off = the exact forward with its blocking read-back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
@@ -210,6 +213,8 @@ def main():
 
     _lib.load()
     rasterizer.set_option("fast_exp", not args.exact_exp)
+    if args.sync_free != "default":
+        rasterizer.set_option("sync_free", False if args.sync_free == "off" else "validated")
     N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2
     g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree, log_scale_mean=math.log(args.scale))
     if args.scene == "heavy":
@@ -291,41 +296,58 @@ def main():
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
 
-    def make_batch_runner(K):
-        """camera batch > 1: K independent views in flight, each host thread with its own HIP stream and its
-        own parameter replica handles (gradients accumulate per thread; a trainer would sum them before its optimizer step)."""
+    def make_batch_runner(K, host_threads=False):
+        """camera batch > 1: K independent views in flight on K HIP streams, each stream with its own parameter
+        replica handles (gradients accumulate per stream; a trainer would sum them before its optimizer step).  Default: ONE
+        host thread issues view i onto stream i % K through the sync-free forward (lg_forward_bounded: nothing is read back);
+        host_threads=True is the round-1 scheme (a host thread per stream, each blocking in its own read-back of R)."""
         import threading
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
         from lightgaussian_amd.parallel import _LeafView
-        replicas = [_LeafView(pc) for _ in range(K)]   # per-thread autograd leaves sharing the parameters' storage (no copies)
+        replicas = [_LeafView(pc) for _ in range(K)]   # per-stream autograd leaves sharing the parameters' storage (no copies)
+
+        def one(w, i):
+            g = replicas[w]
+            k = my_views[i % len(my_views)]
+            if args.mode == "fwdbwd":
+                if k not in gts:
+                    k = next(iter(gts))
+                for p in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity):
+                    p.grad = None
+                photometric(render(cams[k], g, pipe, bg)["render"], gts[k]).backward()
+            else:
+                with torch.no_grad():
+                    render(cams[k], g, pipe, bg)
 
         def run(w, first, count):
             torch.cuda.set_device(dev)
-            g = replicas[w]
-            gp = [g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
             with torch.cuda.stream(streams[w]):
                 for i in range(first + w, first + count, K):
-                    k = my_views[i % len(my_views)]
-                    if args.mode == "fwdbwd":
-                        if k not in gts:
-                            k = next(iter(gts))
-                        for p in gp:
-                            p.grad = None
-                        photometric(render(cams[k], g, pipe, bg)["render"], gts[k]).backward()
-                    else:
-                        with torch.no_grad():
-                            render(cams[k], g, pipe, bg)
+                    one(w, i)
 
         def batch(first, count):
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
-            th = [threading.Thread(target=run, args=(w, first, count)) for w in range(K)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
+            if host_threads:
+                th = [threading.Thread(target=run, args=(w, first, count)) for w in range(K)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+            else:
+                prev = rasterizer._OPTIONS["sync_free"]
+                rasterizer.set_option("sync_free", True)
+                rasterizer.pending_status()
+                try:
+                    for i in range(first, first + count):
+                        with torch.cuda.stream(streams[(i - first) % K]):
+                            one((i - first) % K, i)
+                finally:
+                    rasterizer.set_option("sync_free", prev)
             for st in streams:
                 torch.cuda.current_stream(dev).wait_stream(st)
+            if not host_threads and rasterizer.pending_overflow():
+                raise RuntimeError("a sync-free view outgrew its binning capacity during the bench (capacity margin too small)")
         return batch
 
     def barrier():
@@ -448,6 +470,9 @@ def main():
                                    f"{args.mode} through gaussian_renderer.render, {args.views}-camera orbit",
                        "n_gaussians": N, "width": W, "height": H, "mode": args.mode, "views": args.views,
                        "visible_gaussians": vis, "tile_instances": R, "exp": "canonical" if (args.exact_exp or args.mode == "count") else "hardware",
+                       "forward": {False: "exact (lg_forward: blocking read-back of the instance count)", "validated": "bounded + validated "
+                                   "(lg_forward_bounded with host status: capacity from earlier views, status read after the view is enqueued)",
+                                   True: "bounded, nothing read back"}[rasterizer._OPTIONS["sync_free"]],
                        "getters": "evaluated once per pass by torch and reused for every view (prune._FrozenGetters)" if args.mode == "count" else
                                   "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
                                   "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
@@ -558,16 +583,20 @@ def main():
 
     # ---- camera batch of 3: independent views in flight (informational; `value` above is one view per step, as the reference trains) ----
     if rank == 0 and args.mode in ("fwdbwd", "fwd") and args.views_in_flight == 1 and not args.no_literal:
-        batch3 = make_batch_runner(3)
-        batch3(0, 6)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        batch3(6, 60)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 60
+        def batch_rate(runner):
+            runner(0, 6)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner(6, 90)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 90
+        dt = batch_rate(make_batch_runner(3))
+        dt_thr = batch_rate(make_batch_runner(3, host_threads=True))
         result["camera_batch_3"] = {"views_per_s_per_gpu": round(1.0 / dt, 2), "ms_per_view": round(dt * 1e3, 4),
-                                    "note": "three independent views in flight per GPU (host threads x HIP streams, gradient accumulation "
-                                            "semantics): the VALU-bound blend of one view overlaps the memory-bound stages of another"}
+                                    "host_threads_variant_views_per_s": round(1.0 / dt_thr, 2),
+                                    "note": "three independent views in flight per GPU on three HIP streams, issued by ONE host thread through the "
+                                            "sync-free forward (gradient accumulation semantics): the VALU-bound blend of one view overlaps the "
+                                            "memory-bound stages of another; host_threads_variant = round 1's thread-per-stream scheme"}
 
     # ---- cpu_baseline leg: the oracle on the host cores, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

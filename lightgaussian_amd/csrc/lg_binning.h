@@ -12,71 +12,80 @@
 //       were laid out for (both can only fire in the capacity-bounded forward, whose host side knows neither number);
 //       every later kernel of the view returns at once when [0] != 0
 //   [1] any prefiltered violation (bit 31 of the per-workgroup words)   [2] largest depth bit pattern   [3] R
-// Loads are issued 8 chunks ahead: a single workgroup walking 47k words pays one memory latency per dependent step.
 #define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
-#define LG_SCAN_AHEAD 8
-
+// One workgroup: thread t owns `per` consecutive words (a multiple of 4: 16-byte loads), so the whole array is fetched in
+// ONE memory round trip (all loads of a thread in flight together), reduced, block-scanned through LDS, and fetched again
+// (cache-hot) for the write-out: two round trips + one block scan instead of one round trip per 1024 words (the first
+// version: 40 us at C3, as much as the hipCUB scan + reduction it replaced).
 __global__ void __launch_bounds__(1024)
 lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ blk_off,
                uint32_t capacity, int depth_bits, uint32_t* __restrict__ counters)
 {
-    __shared__ uint32_t wsum[LG_SCAN_AHEAD][16];
-    __shared__ uint32_t wmax[16], wflag[16];
+    __shared__ uint32_t wsum[16], wmax[16], wflag[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t m = 0, f = 0, carry = 0;
-    uint32_t overflow = 0;                        // the running sum passed 2^32 (an instance count no buffer could hold)
-    for (int base = 0; base < nblk; base += 1024 * LG_SCAN_AHEAD) {
-        uint32_t v[LG_SCAN_AHEAD], inc[LG_SCAN_AHEAD];
-#pragma unroll
-        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
-            const int i = base + c * 1024 + (int)tid;
-            v[c] = i < nblk ? blk_sum[i] : 0u;
-            const uint32_t d = i < nblk ? blk_dmax[i] : 0u;
-            m = max(m, d & 0x7FFFFFFFu);
-            f |= d >> 31;
-        }
-#pragma unroll
-        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
-            uint32_t x = v[c];
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const uint32_t o = __shfl_up(x, s, 64);
-                if ((int)lane >= s) x += o;
+    const int per = (((nblk + 1023) / 1024) + 3) & ~3;
+    const int i0 = (int)tid * per;
+    uint32_t sum = 0, m = 0, f = 0;
+    for (int q = 0; q < per; q += 4) {
+        const int i = i0 + q;
+        if (i + 3 < nblk) {
+            const uint4 v = *reinterpret_cast<const uint4*>(blk_sum + i);
+            const uint4 d = *reinterpret_cast<const uint4*>(blk_dmax + i);
+            sum += (v.x + v.y) + (v.z + v.w);
+            m = max(max(m, d.x & 0x7FFFFFFFu), max(d.y & 0x7FFFFFFFu, max(d.z & 0x7FFFFFFFu, d.w & 0x7FFFFFFFu)));
+            f |= (d.x | d.y | d.z | d.w) >> 31;
+        } else {
+            for (int k = i; k < nblk && k < i + 4; k++) {
+                sum += blk_sum[k];
+                const uint32_t d = blk_dmax[k];
+                m = max(m, d & 0x7FFFFFFFu);
+                f |= d >> 31;
             }
-            inc[c] = x;
-            if (lane == 63u) wsum[c][wave] = x;
         }
-        __syncthreads();
+    }
+    // block-wide exclusive scan of the per-thread sums (64-bit running total: an overflow past 2^32 must be seen)
+    uint32_t inc = sum;
 #pragma unroll
-        for (int c = 0; c < LG_SCAN_AHEAD; c++) {
-            uint32_t woff = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < 16; w++) {
-                const uint32_t t = wsum[c][w];
-                woff += (w < (int)wave) ? t : 0u;
-                total += t;
-            }
-            const int i = base + c * 1024 + (int)tid;
-            if (i < nblk) blk_off[i] = carry + woff + inc[c] - v[c];
-            const uint32_t nc = carry + total;
-            overflow |= (nc < carry) ? 1u : 0u;
-            carry = nc;
-        }
-        __syncthreads();
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = __shfl_up(inc, s, 64);
+        if ((int)lane >= s) inc += o;
     }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
-    if (lane == 0u) { wmax[wave] = m; wflag[wave] = f; }
+    if (lane == 63u) { wsum[wave] = inc; wmax[wave] = m; wflag[wave] = f; }
     __syncthreads();
+    uint64_t total = 0;
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t t = wsum[w];
+        woff += (w < (int)wave) ? t : 0u;
+        total += t;
+        m = max(m, wmax[w]); f |= wflag[w];
+    }
+    uint32_t run = woff + inc - sum;
+    for (int q = 0; q < per; q += 4) {
+        const int i = i0 + q;
+        if (i + 3 < nblk) {
+            const uint4 v = *reinterpret_cast<const uint4*>(blk_sum + i);
+            uint4 o;
+            o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            *reinterpret_cast<uint4*>(blk_off + i) = o;
+        } else {
+            for (int k = i; k < nblk && k < i + 4; k++) { blk_off[k] = run; run += blk_sum[k]; }
+        }
+    }
     if (tid == 0) {
-        for (int w = 1; w < 16; w++) { m = max(m, wmax[w]); f |= wflag[w]; }
+        // (per-wave sums can wrap individually only if the total does: instance counts are < 2^32 per wave by construction)
+        const bool overflow = total > 0xFFFFFFFFull;
         const uint32_t dspan = m > LG_DEPTH_BIAS ? m - LG_DEPTH_BIAS : 0u;
-        uint32_t abort = (carry > capacity || overflow) ? 1u : 0u;
+        uint32_t abort = (total > (uint64_t)capacity) ? 1u : 0u;
         if (depth_bits < 32 && (dspan >> depth_bits) != 0u) abort |= 2u;
         counters[0] = abort;
         counters[1] = f;
         counters[2] = m;
-        counters[3] = overflow ? 0xFFFFFFFFu : carry;
+        counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)total;
     }
 }
 
@@ -91,7 +100,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 // instruction; the thread-per-Gaussian version wrote one scattered 8-byte store per lane: WRITE_SIZE 2.3x the key
 // bytes).  The keys are in registers here, so the digit histograms of all radix passes are accumulated on the spot (LDS
 // atomics, flushed once per workgroup): the sort needs no counting pass over the keys.  Persistent grid: a workgroup's 4
-// waves walk K1 workgroups b = 4 blockIdx + wave, + 4 gridDim, ...
+// waves walk groups of four K1 workgroups g = 4 blockIdx + wave, + 4 gridDim, ...
 template <bool PACKED>
 __global__ void __launch_bounds__(256)
 lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
@@ -111,61 +120,79 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
     }
     if (counters[0] != 0u) return;                 // view aborted by lg_scan_blocks (capacity-bounded forward)
     const int sh = depth_bits + gid_bits;
-    for (int b = blockIdx.x * 4 + (int)wave; b < nblk; b += gridDim.x * 4) {
-        const int i = b * 64 + (int)lane;
-        const uint32_t t = i < N ? touched[i] : 0u;
-        uint32_t inc = t;
+    // a wave takes FOUR consecutive K1 workgroups per iteration and issues all of their loads (instance counts, base offsets,
+    // tile rectangles) before it touches any of them: one exposed memory round trip per 256 Gaussians instead of two per 64
+    // (the first version, one K1 workgroup per iteration with dependent loads, was latency-bound: 61 us at C3)
+    const int ngroups = (nblk + 3) / 4;
+    for (int g = blockIdx.x * 4 + (int)wave; g < ngroups; g += gridDim.x * 4) {
+        uint32_t t4[4], base4[4];
+        uint4 r4[4];
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const uint32_t o = __shfl_up(inc, s, 64);
-            if ((int)lane >= s) inc += o;
+        for (int u = 0; u < 4; u++) {
+            const int b = g * 4 + u, i = b * 64 + (int)lane;
+            t4[u] = (b < nblk && i < N) ? touched[i] : 0u;
+            base4[u] = b < nblk ? blk_off[b] : 0u;
         }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        const uint32_t base = blk_off[b];
-        if (i < N) offsets[i] = base + inc;        // inclusive scan, as K9 expects (slot base = offsets - touched)
-        if (total == 0u) continue;                 // wave-uniform
-        const uint32_t exc = inc - t;
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (t) {
-            r = tinfo[i];
-            tinfo[i].w = base + exc;               // slot base of this Gaussian's instances (lg_slot_of: row address in the backward)
-        }
-        s_exc[wave][lane] = exc;
-        s_xy[wave][lane] = r.x;
-        s_w[wave][lane] = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
-        if (PACKED) {
-            const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
-            s_lo[wave][lane] = (uint32_t)low;
-            s_hi[wave][lane] = (uint32_t)(low >> 32);
-        } else {
-            s_lo[wave][lane] = r.z;                // depth bits
-            s_hi[wave][lane] = (uint32_t)i;        // value = Gaussian id
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t p = lane; p < total; p += 64u) {
-            uint32_t j = 0;                        // largest j with exc[j] <= p: the Gaussian that owns instance p
 #pragma unroll
-            for (uint32_t step = 32; step > 0; step >>= 1)
-                if (s_exc[wave][j + step] <= p) j += step;
-            const uint32_t k = p - s_exc[wave][j], w = s_w[wave][j], xy = s_xy[wave][j];
-            const uint32_t ky = k / w, kx = k - ky * w;
-            const uint32_t tile = ((xy >> 16) + ky) * (uint32_t)gx + (xy & 0xFFFFu) + kx;
-            const uint64_t pos = (uint64_t)base + p;
-            if (PACKED) {
-                const uint64_t key = ((uint64_t)tile << sh) | ((uint64_t)s_hi[wave][j] << 32) | s_lo[wave][j];
-                if (pos < capacity) keys[pos] = key;
-                for (int q = 0; q < passes; q++) {
-                    const int bit = sort_begin + 8 * q, nb = min(8, sort_end - bit);
-                    atomicAdd(&lh[q * 256 + (uint32_t)((key >> bit) & ((1u << nb) - 1u))], 1u);
+        for (int u = 0; u < 4; u++) {
+            const int i = (g * 4 + u) * 64 + (int)lane;
+            r4[u] = make_uint4(0, 0, 0, 0);
+            if (t4[u]) r4[u] = tinfo[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = g * 4 + u, i = b * 64 + (int)lane;
+            const uint32_t t = t4[u], base = base4[u];
+            const uint4 r = r4[u];
+            uint32_t inc = t;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const uint32_t o = __shfl_up(inc, s, 64);
+                if ((int)lane >= s) inc += o;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (b < nblk && i < N) offsets[i] = base + inc;   // inclusive scan, as K9 expects (slot base = offsets - touched)
+            if (total != 0u) {                                 // wave-uniform
+                const uint32_t exc = inc - t;
+                if (t) tinfo[i].w = base + exc;                // slot base of this Gaussian's instances (lg_slot_of: row address in the backward)
+                s_exc[wave][lane] = exc;
+                s_xy[wave][lane] = r.x;
+                s_w[wave][lane] = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
+                if (PACKED) {
+                    const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
+                    s_lo[wave][lane] = (uint32_t)low;
+                    s_hi[wave][lane] = (uint32_t)(low >> 32);
+                } else {
+                    s_lo[wave][lane] = r.z;                    // depth bits
+                    s_hi[wave][lane] = (uint32_t)i;            // value = Gaussian id
                 }
-            } else if (pos < capacity) {
-                keys[pos] = ((uint64_t)tile << 32) | s_lo[wave][j];
-                vals[pos] = s_hi[wave][j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t p = lane; p < total; p += 64u) {
+                    uint32_t j = 0;                            // largest j with exc[j] <= p: the Gaussian that owns instance p
+#pragma unroll
+                    for (uint32_t step = 32; step > 0; step >>= 1)
+                        if (s_exc[wave][j + step] <= p) j += step;
+                    const uint32_t k = p - s_exc[wave][j], w = s_w[wave][j], xy = s_xy[wave][j];
+                    const uint32_t ky = k / w, kx = k - ky * w;
+                    const uint32_t tile = ((xy >> 16) + ky) * (uint32_t)gx + (xy & 0xFFFFu) + kx;
+                    const uint64_t pos = (uint64_t)base + p;
+                    if (PACKED) {
+                        const uint64_t key = ((uint64_t)tile << sh) | ((uint64_t)s_hi[wave][j] << 32) | s_lo[wave][j];
+                        if (pos < capacity) keys[pos] = key;
+                        for (int q = 0; q < passes; q++) {
+                            const int bit = sort_begin + 8 * q, nb = min(8, sort_end - bit);
+                            atomicAdd(&lh[q * 256 + (uint32_t)((key >> bit) & ((1u << nb) - 1u))], 1u);
+                        }
+                    } else if (pos < capacity) {
+                        keys[pos] = ((uint64_t)tile << 32) | s_lo[wave][j];
+                        vals[pos] = s_hi[wave][j];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();               // the next K1 workgroup overwrites this wave's LDS rows
             }
         }
-        __builtin_amdgcn_wave_barrier();           // the next K1 workgroup overwrites this wave's LDS rows
     }
     if (PACKED) {
         __syncthreads();

@@ -5,6 +5,7 @@
 #include "lg_host.h"
 #include "lg_wave.h"
 #include "lg_binning.h" // lg_slot_of
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // tile <-> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).
@@ -103,75 +104,80 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
     // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
     const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
-    float Cs0 = 0.0f, Cs1 = 0.0f, Cs2 = 0.0f;
-    uint32_t seg = 0;
-    float4* ck = nullptr;
-    if (longt) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + (((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u));
-
-    for (uint32_t base = range.x; base < range.y; base += LG_Q) {
-        if (longt && base != range.x && (base - range.x) % (uint32_t)S == 0u) {
-            ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
-            seg++; Cs0 = Cs1 = Cs2 = 0.0f;
-        }
-        if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
-        const uint32_t idx = base + lane;
-        bool hit = false;
-        float4 r0, r1, r2;
-        if (idx < range.y) {
-            const uint32_t id = (uint32_t)entries[idx] & gid_mask;
-            r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
-            // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
-            hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
-        }
-        uint64_t mask = __ballot(hit);
-        if (mask == 0) continue;
-        if (hit) {
-            const uint32_t pos = prefix_popc(mask);
-            q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
-        }
-        __builtin_amdgcn_wave_barrier();
-        int mycnt = 0;
-        float myf = 0.0f;
-        uint32_t j = 0;
-        const uint32_t rel = base - range.x + 1; // contributor index of source lane 0
-        while (mask) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
-            float alpha = 0.0f, Tprev = T, w = 0.0f;
-            const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha, w) ? 1 : 0;
-            if (longt) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
+    // the walk exists twice: tiles of one segment (every tile of the uniform benchmark scene) run the LONG = false copy,
+    // which carries neither the segment accumulators nor the boundary test
+    auto walk = [&](auto long_tag) {
+        constexpr bool LONG = decltype(long_tag)::value;
+        float Cs0 = 0.0f, Cs1 = 0.0f, Cs2 = 0.0f;
+        uint32_t seg = 0;
+        float4* ck = nullptr;
+        if (LONG) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + (((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u));
+        for (uint32_t base = range.x; base < range.y; base += LG_Q) {
+            if (LONG && base != range.x && (base - range.x) % (uint32_t)S == 0u) {
+                ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
+                seg++; Cs0 = Cs1 = Cs2 = 0.0f;
+            }
+            if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
+            const uint32_t idx = base + lane;
+            bool hit = false;
+            float4 r0, r1, r2;
+            if (idx < range.y) {
+                const uint32_t id = (uint32_t)entries[idx] & gid_mask;
+                r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
+                // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
+                hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
+            }
+            uint64_t mask = __ballot(hit);
+            if (mask == 0) continue;
+            if (hit) {
+                const uint32_t pos = prefix_popc(mask);
+                q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int mycnt = 0;
+            float myf = 0.0f;
+            uint32_t j = 0;
+            const uint32_t rel = base - range.x + 1; // contributor index of source lane 0
+            while (mask) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
+                float alpha = 0.0f, Tprev = T, w = 0.0f;
+                const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha, w) ? 1 : 0;
+                if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
+                if (COUNT) {
+                    const uint64_t cm = __ballot(res == 1);
+                    if (lane == j) mycnt = (int)__popcll(cm);
+                    if (FSCORE) {
+                        float wv = (res == 1) ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
+                        wv = wave_sum_to_lane63(wv);
+                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
+                        if (lane == j) myf = tot;
+                    }
+                }
+                j++;
+            }
             if (COUNT) {
-                const uint64_t cm = __ballot(res == 1);
-                if (lane == j) mycnt = (int)__popcll(cm);
-                if (FSCORE) {
-                    float wv = (res == 1) ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
-                    wv = wave_sum_to_lane63(wv);
-                    const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
-                    if (lane == j) myf = tot;
+                // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
+                if (lane < j && mycnt > 0) {
+                    const uint32_t id = __float_as_uint(q2[wave][lane].w);
+                    atomicAdd(&count[id], mycnt);
+                    if (FSCORE) atomicAdd(&fscore[id], myf);
                 }
             }
-            j++;
+            __builtin_amdgcn_wave_barrier();
         }
-        if (COUNT) {
-            // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
-            if (lane < j && mycnt > 0) {
-                const uint32_t id = __float_as_uint(q2[wave][lane].w);
-                atomicAdd(&count[id], mycnt);
-                if (FSCORE) atomicAdd(&fscore[id], myf);
+        if (LONG) {
+            // the current segment's record, and -- when the wave stopped early -- those of the segments it never entered
+            // (nothing contributed there: T stays, colour 0), so that every record of the tile is valid for every pixel
+            const uint32_t nseg = (range.y - range.x + (uint32_t)S - 1u) / (uint32_t)S;
+            for (; seg < nseg; seg++) {
+                ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
+                Cs0 = Cs1 = Cs2 = 0.0f;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (longt) {
-        // the current segment's record, and -- when the wave stopped early -- those of the segments it never entered
-        // (nothing contributed there: T stays, colour 0), so that every record of the tile is valid for every pixel
-        const uint32_t nseg = (range.y - range.x + (uint32_t)S - 1u) / (uint32_t)S;
-        for (; seg < nseg; seg++) {
-            ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
-            Cs0 = Cs1 = Cs2 = 0.0f;
-        }
-    }
+    };
+    if (longt) walk(std::true_type{}); else walk(std::false_type{});
     if (COLOR && inside) {   // !COLOR: forward-only significance pass, nothing per pixel is kept
         const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
         final_T[pid] = T;

@@ -32,6 +32,9 @@
 #define LG_SORT_WAVES (LG_SORT_BLOCK / 64)
 #define LG_SORT_TILE (LG_SORT_BLOCK * LG_SORT_ITEMS)
 #define LG_SORT_MAX_PASSES 8 // 64 key bits / 8
+#ifndef LG_SORT_WINDOW
+#define LG_SORT_WINDOW 16    // predecessors examined per look-back round trip
+#endif
 #define LG_SORT_FLAG_AGG 1u
 #define LG_SORT_FLAG_PREFIX 2u
 #define LG_SORT_VALUE_MASK 0x3FFFFFFFu
@@ -149,11 +152,13 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
     // ---- per-digit: scan over the waves, look-back over the tiles, scans over the digits ----
     uint32_t run = 0, gh = 0;
     if (tid < 256) {
-#pragma unroll 4
+        uint32_t cw[LG_SORT_WAVES];
+#pragma unroll
+        for (int w = 0; w < LG_SORT_WAVES; w++) cw[w] = wcnt[w][tid];       // all reads in flight, then the running sum
+#pragma unroll
         for (int w = 0; w < LG_SORT_WAVES; w++) {
-            const uint32_t c = wcnt[w][tid];
             wcnt[w][tid] = (unsigned short)run;                            // exclusive over the waves of this tile
-            run += c;
+            run += cw[w];
         }
         gh = hist[tid];
         // publish the tile's aggregate before looking back: nobody ever waits for more than this store
@@ -177,18 +182,35 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
         const uint32_t gb = goff[tid] + cg;                                 // global start of digit tid (all tiles)
         uint32_t excl = 0;
         if (tile > 0) {
-            // (the TOTAL number of polls of a thread is bounded: a predecessor always publishes -- ticket order -- so the
-            // bound is never reached; it turns a would-be hang of the device into a wrong result that the tests catch)
+            // Windowed look-back.  All tiles of a pass are co-resident and publish their aggregates at about the same time, so
+            // a tile that walks back ONE predecessor per memory round trip needs ~sqrt(2 * tiles) dependent round trips
+            // (~30 at 500 tiles, ~1 us each: most of a pass).  Reading LG_SORT_WINDOW predecessors per round trip (independent
+            // loads, all in flight) cuts that to ~sqrt(2 * tiles / window).  States are consumed nearest-first; a zero
+            // (unpublished) state is re-polled alone.  (The TOTAL number of polls of a thread is bounded: a predecessor
+            // always publishes -- ticket order -- so the bound is never reached; it turns a would-be hang of the device into a
+            // wrong result that the tests catch.)
             uint32_t budget = 1u << 18;
-            for (int64_t b = (int64_t)tile - 1; b >= 0; b--) {
-                uint32_t s = lg_ld_state(&states[(size_t)b * 256 + tid]);
-                while ((s >> 30) == 0u && budget > 0u) {
-                    budget--;
-                    __builtin_amdgcn_s_sleep(2);
-                    s = lg_ld_state(&states[(size_t)b * 256 + tid]);
+            int64_t b = (int64_t)tile - 1;
+            bool found = false;
+            while (b >= 0 && !found) {
+                uint32_t win[LG_SORT_WINDOW];
+#pragma unroll
+                for (int k = 0; k < LG_SORT_WINDOW; k++)
+                    win[k] = (b - k >= 0) ? lg_ld_state(&states[(size_t)(b - k) * 256 + tid]) : (LG_SORT_FLAG_PREFIX << 30);
+#pragma unroll
+                for (int k = 0; k < LG_SORT_WINDOW; k++) {
+                    if (!found) {
+                        uint32_t sv = win[k];
+                        while ((sv >> 30) == 0u && budget > 0u) {
+                            budget--;
+                            __builtin_amdgcn_s_sleep(2);
+                            sv = lg_ld_state(&states[(size_t)(b - k) * 256 + tid]);
+                        }
+                        excl += sv & LG_SORT_VALUE_MASK;
+                        found = (sv >> 30) == LG_SORT_FLAG_PREFIX || budget == 0u;
+                    }
                 }
-                excl += s & LG_SORT_VALUE_MASK;
-                if ((s >> 30) == LG_SORT_FLAG_PREFIX || budget == 0u) break;
+                b -= LG_SORT_WINDOW;
             }
         }
         lg_st_state(&states[(size_t)tile * 256 + tid], (LG_SORT_FLAG_PREFIX << 30) | ((excl + run) & LG_SORT_VALUE_MASK));

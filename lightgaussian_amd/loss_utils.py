@@ -44,10 +44,13 @@ class _L1SSIM(torch.autograd.Function):
                                        C.c_void_p(stream)))
         ctx.save_for_backward(img, gt, state)
         ctx.dims = (planes, H, W)
+        ctx.token = {"consumed": False}      # shared with the memo of _both(): a graph that ran backward is not handed out again
+        _L1SSIM.last_token = ctx.token
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim):
+        ctx.token["consumed"] = True
         img, gt, state = ctx.saved_tensors
         planes, H, W = ctx.dims
         lib = _lib.load()
@@ -71,20 +74,28 @@ def _prep(img, gt):
     return img.contiguous().float(), gt.detach().contiguous().float()
 
 
-_memo = threading.local()  # .last = (weakref(img), version, weakref(gt), version, (l1, ssim, grad_mode)); per host thread
+_memo = threading.local()  # .last = (weakref(img), version, weakref(gt), version, l1, ssim, grad mode, token); per host thread
 
 
-def _both(img, gt):
+def _both(img, gt, last_use=False):
     """(l1, ssim) of one fused launch; memoised on tensor identity + version so that the reference's
-    l1_loss(image, gt) ... ssim(image, gt) pair costs one forward and one backward launch."""
+    l1_loss(image, gt) ... ssim(image, gt) pair costs one forward and one backward launch.  The memo is dropped as soon as
+    the pair is complete (last_use: ssim() and l1_dssim_loss() hand out the second output), so the image-sized saved state
+    lives no longer than the caller's own references, and it is void once that graph has run backward: l1_loss(x, y)
+    .backward() twice in a row recomputes, as the reference does."""
     last = getattr(_memo, "last", None)
     if last is not None:
-        wi, vi, wg, vg, res = last
-        if wi() is img and wg() is gt and vi == img._version and vg == gt._version and torch.is_grad_enabled() == res[2]:
-            return res[0], res[1]
+        wi, vi, wg, vg, l1, ss, mode, token = last
+        if (wi() is img and wg() is gt and vi == img._version and vg == gt._version and torch.is_grad_enabled() == mode
+                and not token["consumed"]):
+            if last_use:
+                _memo.last = None
+            return l1, ss
     a, b = _prep(img, gt)
     l1, ss = _L1SSIM.apply(a, b)
-    _memo.last = (weakref.ref(img), img._version, weakref.ref(gt), gt._version, (l1, ss, torch.is_grad_enabled()))
+    token = _L1SSIM.last_token if (torch.is_grad_enabled() and a.requires_grad) else {"consumed": False}
+    _memo.last = None if last_use else (weakref.ref(img), img._version, weakref.ref(gt), gt._version, l1, ss,
+                                        torch.is_grad_enabled(), token)
     return l1, ss
 
 
@@ -107,14 +118,31 @@ def l2_loss(network_output, gt):
 
 def ssim(img1, img2, window_size=11, size_average=True):
     """utils/loss_utils.py:46-85: mean SSIM with the 11x11 Gaussian window (sigma 1.5), zero padding."""
-    if window_size != 11:
-        raise NotImplementedError("the HIP kernel implements the reference's only window: 11x11, sigma 1.5")
-    if not size_average:
-        raise NotImplementedError("size_average=False (per-image means) is not used by the reference's trainers")
-    return _both(img1, img2)[1]
+    if window_size != 11 or not size_average:
+        return _ssim_general(img1, img2, window_size, size_average)
+    return _both(img1, img2, last_use=True)[1]
+
+
+def _ssim_general(img1, img2, window_size, size_average):
+    """The argument combinations no trainer of the reference uses (another window size, per-image means): the formula of
+    utils/loss_utils.py:26-85 in plain torch ops on the images' device -- normalised Gaussian window of sigma 1.5, grouped
+    conv2d with zero padding window_size // 2, C1 = 0.01^2, C2 = 0.03^2.  The fused HIP kernel covers the 11 x 11 / mean case."""
+    import math
+    import torch.nn.functional as F
+    channel = img1.size(-3)
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / float(2 * 1.5 ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    window = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous().to(img1.device).type_as(img1)
+    conv = lambda t: F.conv2d(t, window, padding=window_size // 2, groups=channel)  # noqa: E731
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq, sigma2_sq, sigma12 = conv(img1 * img1) - mu1_sq, conv(img2 * img2) - mu2_sq, conv(img1 * img2) - mu1_mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + c1) * (2 * sigma12 + c2)) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
 
 
 def l1_dssim_loss(image, gt, lambda_dssim):
     """loss = (1 - lambda) * L1 + lambda * (1 - SSIM)  (prune_finetune.py:161-164).  Returns (loss, Ll1)."""
-    l1, ss = _both(image, gt)
+    l1, ss = _both(image, gt, last_use=True)
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss), l1

@@ -124,3 +124,22 @@ def test_loss_gradient_reaches_the_gaussians_through_render():
     loss.backward()
     g = pc._xyz.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_repeated_backward_recomputes_and_general_ssim_arguments():
+    """l1_loss(x, y).backward() twice in a row must work (the memo is void once its graph ran backward), and the
+    argument combinations the trainers never use (another window, per-image means) follow the reference formula."""
+    x = torch.rand(3, 40, 60, device=DEV, requires_grad=True); y = torch.rand(3, 40, 60, device=DEV)
+    LU.l1_loss(x, y).backward()
+    g1 = x.grad.clone(); x.grad = None
+    LU.l1_loss(x, y).backward()
+    assert torch.equal(g1, x.grad)
+    a = LU.l1_loss(x, y); b = LU.ssim(x, y)                       # the reference's pair: one node, then the memo is dropped
+    assert LU._memo.last is None
+    (a + b).backward()
+    xb = torch.rand(2, 3, 40, 60, device=DEV); yb = torch.rand(2, 3, 40, 60, device=DEV)
+    per_image = LU.ssim(xb, yb, size_average=False)
+    assert per_image.shape == (2,)
+    for i in range(2):
+        assert float(per_image[i]) == pytest.approx(float(LU.ssim(xb[i], yb[i])), rel=1e-5)
+    assert float(LU.ssim(xb[0], yb[0], window_size=7)) == pytest.approx(LO.ssim(xb[0].cpu().numpy(), yb[0].cpu().numpy()), abs=0.05)
