@@ -167,6 +167,19 @@ int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii
                 float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                 float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream);
 
+/* lg_backward with the per-Gaussian stage (K9) split into `chunks` launches over consecutive Gaussian ranges.  on_chunk(user,
+ * first, count) is called on the HOST right after the launch covering Gaussians [first, first + count) has been enqueued: from
+ * that point of `stream` on, rows [first, first + count) of every gradient tensor are final.  A data-parallel trainer
+ * records an event there and all-reduces those rows on a side stream while K9 computes the next range (SURVEY 8f row 3:
+ * gradient all-reduce overlapped with K7-K9; lightgaussian_amd.parallel.OverlappedGradAllReduce).  The reference's
+ * distill_train.py:124-166 has no such hook -- its extension returns all gradients at once. */
+typedef void (*lg_chunk_fn)(void* user, int32_t first, int32_t count);
+int lg_backward_chunked(const lg_view* view, const lg_gaussians* g, const int32_t* radii, const void* geom, const void* binning,
+                        const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                        float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                        float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream, int32_t chunks, lg_chunk_fn on_chunk,
+                        void* user);
+
 /* score[j] = seqsum32(weight[j], count[j]) on the device (weight NULL => 1.0).  Used by the sharded
  * prune pass to rebuild per-view scores from integer counts. */
 int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream);

@@ -28,7 +28,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
-           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length"]
+           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked"]
 
 
 class lg_view(C.Structure):
@@ -53,6 +53,7 @@ class lg_stats(C.Structure):
 
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)
 
 
 def build(force=False, verbose=False):
@@ -88,6 +89,8 @@ def load():
                                      P(C.c_int64), vp]
     lib.lg_backward.restype = C.c_int
     lib.lg_backward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 9 + [vp, vp]
+    lib.lg_backward_chunked.restype = C.c_int
+    lib.lg_backward_chunked.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, vp, vp, C.c_int64, vp] + [vp] * 9 + [vp, vp, C.c_int32, CHUNK_FN, vp]
     lib.lg_score_from_count.restype = C.c_int
     lib.lg_score_from_count.argtypes = [C.c_int32, vp, vp, vp, vp]
     lib.lg_loss_state_bytes.restype = C.c_size_t; lib.lg_loss_state_bytes.argtypes = [C.c_int32] * 3

@@ -241,12 +241,12 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         {
             ProfScope ps(prof, "duplicate", stream);
-            const int dgrid = std::max(1, std::min((nblk + 3) / 4, 1024));
+            const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), 256));
             if (kp.packed)
-                lg_duplicate<true><<<dgrid, 256, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
+                lg_duplicate<true><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
                                                               geo.blk_off, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);
             else
-                lg_duplicate<false><<<dgrid, 256, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.counters, geo.offsets,
+                lg_duplicate<false><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.counters, geo.offsets,
                                                                geo.tinfo, bin.keys_in, bin.vals_in, ntiles, bin.ranges, nullptr);
         }
         KCHECK("lg_duplicate");
@@ -330,10 +330,10 @@ extern "C" int lg_forward_bounded(const lg_view* view, const lg_gaussians* g, vo
     return forward_impl(view, g, geom, img, nullptr, nullptr, &b, weight_policy, out_color, out_radii, out_count, out_score, nullptr, nullptr, stream);
 }
 
-extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
-                           const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
-                           float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                           float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p)
+static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
+                         const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                         float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                         float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p, int chunks, lg_chunk_fn on_chunk, void* user)
 {
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
@@ -377,18 +377,48 @@ extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_
     }
     KCHECK("lg_blend_bwd");
     {
+        // K9 runs over Gaussian ranges: `chunks` launches of consecutive 64-Gaussian workgroups.  After each launch is enqueued
+        // the caller is told (on_chunk): rows [first, first + count) of every gradient tensor are final once the stream reaches
+        // that point -- a data-parallel trainer starts their all-reduce there, while K9 computes the next range.
         ProfScope ps(prof, "preprocess_bwd", stream);
+        const int nblk = (N + LG_PP - 1) / LG_PP;
+        if (chunks < 1) chunks = 1;
+        if (chunks > nblk) chunks = nblk;
+        const int per = (nblk + chunks - 1) / chunks;
+        for (int first_blk = 0; first_blk < nblk; first_blk += per) {
+            const int nb = std::min(per, nblk - first_blk);
 #define LAUNCH_PPB(RAWP)                                                                                                             \
-    lg_preprocess_bwd<RAWP><<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(                                                           \
-        N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
+    lg_preprocess_bwd<RAWP><<<nb, LG_PP, 0, stream>>>(                                                                                \
+        N, first_blk, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
         g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec, geo.aux,   \
         geo.counters, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
-        if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
+            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
 #undef LAUNCH_PPB
+            if (on_chunk) on_chunk(user, first_blk * LG_PP, std::min(N - first_blk * LG_PP, nb * LG_PP));
+        }
     }
     KCHECK("lg_preprocess_bwd");
     return LG_OK;
+}
+
+extern "C" int lg_backward(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
+                           const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                           float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                           float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p)
+{
+    return backward_impl(v, g, radii, geom_p, bin_p, img_p, R, dL_dcolor, dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity,
+                         dL_dscales, dL_drotations, dL_dcov3D, dL_dshs_rest, scratch, stream_p, 1, nullptr, nullptr);
+}
+
+extern "C" int lg_backward_chunked(const lg_view* v, const lg_gaussians* g, const int32_t* radii, const void* geom_p, const void* bin_p,
+                                   const void* img_p, int64_t R, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
+                                   float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                                   float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream_p, int32_t chunks,
+                                   lg_chunk_fn on_chunk, void* user)
+{
+    return backward_impl(v, g, radii, geom_p, bin_p, img_p, R, dL_dcolor, dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity,
+                         dL_dscales, dL_drotations, dL_dcov3D, dL_dshs_rest, scratch, stream_p, chunks, on_chunk, user);
 }
 
 extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream_p)

@@ -13,79 +13,92 @@
 //       every later kernel of the view returns at once when [0] != 0
 //   [1] any prefiltered violation (bit 31 of the per-workgroup words)   [2] largest depth bit pattern   [3] R
 #define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
-// One workgroup: thread t owns `per` consecutive words (a multiple of 4: 16-byte loads), so the whole array is fetched in
-// ONE memory round trip (all loads of a thread in flight together), reduced, block-scanned through LDS, and fetched again
-// (cache-hot) for the write-out: two round trips + one block scan instead of one round trip per 1024 words (the first
-// version: 40 us at C3, as much as the hipCUB scan + reduction it replaced).
+// One workgroup, ONE memory round trip per 65 536 words: thread t owns 64 consecutive words of a round and fetches them with
+// sixteen 16-byte loads that are all in flight together (fully unrolled, no branch between them), keeps them in registers,
+// block-scans the per-thread sums through LDS and writes the exclusive prefixes from the registers.  (A loop with a load per
+// iteration serialises on memory latency: 40 us at C3 for 47 k words, as much as the hipCUB scan + reduction it replaced.)
+// The arrays are 256-byte aligned and padded (carve_geom), so an aligned 16-byte load that straddles the end is in bounds;
+// the words past nblk are masked.
 __global__ void __launch_bounds__(1024)
 lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ blk_off,
                uint32_t capacity, int depth_bits, uint32_t* __restrict__ counters)
 {
     __shared__ uint32_t wsum[16], wmax[16], wflag[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = (((nblk + 1023) / 1024) + 3) & ~3;
-    const int i0 = (int)tid * per;
-    uint32_t sum = 0, m = 0, f = 0;
-    for (int q = 0; q < per; q += 4) {
-        const int i = i0 + q;
-        if (i + 3 < nblk) {
-            const uint4 v = *reinterpret_cast<const uint4*>(blk_sum + i);
-            const uint4 d = *reinterpret_cast<const uint4*>(blk_dmax + i);
-            sum += (v.x + v.y) + (v.z + v.w);
+    uint32_t m = 0, f = 0;
+    uint64_t carry = 0;                          // instances before this round (64-bit: an overflow past 2^32 must be seen)
+    for (int round0 = 0; round0 < nblk; round0 += 65536) {
+        const int i0 = round0 + (int)tid * 64;
+        uint4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = i0 + 4 * q;
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (i < nblk) v[q] = *reinterpret_cast<const uint4*>(blk_sum + i);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = i0 + 4 * q;
+            uint4 d = make_uint4(0, 0, 0, 0);
+            if (i < nblk) d = *reinterpret_cast<const uint4*>(blk_dmax + i);
+            d.y = (i + 1 < nblk) ? d.y : 0u; d.z = (i + 2 < nblk) ? d.z : 0u; d.w = (i + 3 < nblk) ? d.w : 0u;
             m = max(max(m, d.x & 0x7FFFFFFFu), max(d.y & 0x7FFFFFFFu, max(d.z & 0x7FFFFFFFu, d.w & 0x7FFFFFFFu)));
             f |= (d.x | d.y | d.z | d.w) >> 31;
-        } else {
-            for (int k = i; k < nblk && k < i + 4; k++) {
-                sum += blk_sum[k];
-                const uint32_t d = blk_dmax[k];
-                m = max(m, d & 0x7FFFFFFFu);
-                f |= d >> 31;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = i0 + 4 * q;
+            v[q].y = (i + 1 < nblk) ? v[q].y : 0u; v[q].z = (i + 2 < nblk) ? v[q].z : 0u; v[q].w = (i + 3 < nblk) ? v[q].w : 0u;
+            sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(inc, s, 64);
+            if ((int)lane >= s) inc += o;
+        }
+        if (lane == 63u) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        uint64_t total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            woff += (w < (int)wave) ? t : 0u;
+            total += t;
+        }
+        uint32_t run = (uint32_t)carry + woff + inc - sum;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = i0 + 4 * q;
+            uint4 o;
+            o.x = run; o.y = run + v[q].x; o.z = o.y + v[q].y; o.w = o.z + v[q].z;
+            run = o.w + v[q].w;
+            if (i + 3 < nblk) *reinterpret_cast<uint4*>(blk_off + i) = o;
+            else {
+                if (i < nblk) blk_off[i] = o.x;
+                if (i + 1 < nblk) blk_off[i + 1] = o.y;
+                if (i + 2 < nblk) blk_off[i + 2] = o.z;
             }
         }
-    }
-    // block-wide exclusive scan of the per-thread sums (64-bit running total: an overflow past 2^32 must be seen)
-    uint32_t inc = sum;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t o = __shfl_up(inc, s, 64);
-        if ((int)lane >= s) inc += o;
+        carry += total;
+        __syncthreads();
     }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
-    if (lane == 63u) { wsum[wave] = inc; wmax[wave] = m; wflag[wave] = f; }
+    if (lane == 0u) { wmax[wave] = m; wflag[wave] = f; }
     __syncthreads();
-    uint64_t total = 0;
-    uint32_t woff = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-        const uint32_t t = wsum[w];
-        woff += (w < (int)wave) ? t : 0u;
-        total += t;
-        m = max(m, wmax[w]); f |= wflag[w];
-    }
-    uint32_t run = woff + inc - sum;
-    for (int q = 0; q < per; q += 4) {
-        const int i = i0 + q;
-        if (i + 3 < nblk) {
-            const uint4 v = *reinterpret_cast<const uint4*>(blk_sum + i);
-            uint4 o;
-            o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
-            run = o.w + v.w;
-            *reinterpret_cast<uint4*>(blk_off + i) = o;
-        } else {
-            for (int k = i; k < nblk && k < i + 4; k++) { blk_off[k] = run; run += blk_sum[k]; }
-        }
-    }
     if (tid == 0) {
-        // (per-wave sums can wrap individually only if the total does: instance counts are < 2^32 per wave by construction)
-        const bool overflow = total > 0xFFFFFFFFull;
+        for (int w = 1; w < 16; w++) { m = max(m, wmax[w]); f |= wflag[w]; }
+        const bool overflow = carry > 0xFFFFFFFFull;
         const uint32_t dspan = m > LG_DEPTH_BIAS ? m - LG_DEPTH_BIAS : 0u;
-        uint32_t abort = (total > (uint64_t)capacity) ? 1u : 0u;
+        uint32_t abort = (carry > (uint64_t)capacity) ? 1u : 0u;
         if (depth_bits < 32 && (dspan >> depth_bits) != 0u) abort |= 2u;
         counters[0] = abort;
         counters[1] = f;
         counters[2] = m;
-        counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)total;
+        counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
     }
 }
 
@@ -100,22 +113,27 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 // instruction; the thread-per-Gaussian version wrote one scattered 8-byte store per lane: WRITE_SIZE 2.3x the key
 // bytes).  The keys are in registers here, so the digit histograms of all radix passes are accumulated on the spot (LDS
 // atomics, flushed once per workgroup): the sort needs no counting pass over the keys.  Persistent grid: a workgroup's 4
-// waves walk groups of four K1 workgroups g = 4 blockIdx + wave, + 4 gridDim, ...
+// waves walk groups of four K1 workgroups g = waves * blockIdx + wave, + waves * gridDim, ...
+// 1024-thread workgroups, at most one per CU: the digit histograms are flushed with one global atomic per (workgroup, bin),
+// and atomics on one address serialise (~12 ns each): 1024 workgroups of 256 threads cost ~1000 atomics per bin, about as long
+// as the rest of the kernel; 256 workgroups of 1024 threads a quarter of that for the same number of waves.
+#define LG_DUP_THREADS 1024
+#define LG_DUP_WAVES (LG_DUP_THREADS / 64)
 template <bool PACKED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LG_DUP_THREADS)
 lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
              const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ counters,
              uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
              int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t lh[PACKED ? LG_SORT_MAX_PASSES * 256 : 1];
-    __shared__ uint32_t s_exc[4][64], s_xy[4][64], s_w[4][64], s_hi[4][64], s_lo[4][64];
+    __shared__ uint32_t s_exc[LG_DUP_WAVES][64], s_xy[LG_DUP_WAVES][64], s_w[LG_DUP_WAVES][64], s_hi[LG_DUP_WAVES][64], s_lo[LG_DUP_WAVES][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // empty tiles keep {0, 0}: cleared here (this kernel runs before the sort) instead of by a memset
-    for (int t = blockIdx.x * 256 + (int)tid; t < ntiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);
+    for (int t = blockIdx.x * LG_DUP_THREADS + (int)tid; t < ntiles; t += gridDim.x * LG_DUP_THREADS) ranges[t] = make_uint2(0u, 0u);
     const int passes = PACKED ? (sort_end - sort_begin + 7) / 8 : 0;
     if (PACKED) {
-        for (int i = (int)tid; i < passes * 256; i += 256) lh[i] = 0;
+        for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS) lh[i] = 0;
         __syncthreads();
     }
     if (counters[0] != 0u) return;                 // view aborted by lg_scan_blocks (capacity-bounded forward)
@@ -124,7 +142,7 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
     // tile rectangles) before it touches any of them: one exposed memory round trip per 256 Gaussians instead of two per 64
     // (the first version, one K1 workgroup per iteration with dependent loads, was latency-bound: 61 us at C3)
     const int ngroups = (nblk + 3) / 4;
-    for (int g = blockIdx.x * 4 + (int)wave; g < ngroups; g += gridDim.x * 4) {
+    for (int g = blockIdx.x * LG_DUP_WAVES + (int)wave; g < ngroups; g += gridDim.x * LG_DUP_WAVES) {
         uint32_t t4[4], base4[4];
         uint4 r4[4];
 #pragma unroll
@@ -196,7 +214,7 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
     }
     if (PACKED) {
         __syncthreads();
-        for (int i = (int)tid; i < passes * 256; i += 256)
+        for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS)
             if (lh[i]) atomicAdd(&hist[i], lh[i]);
     }
 }

@@ -217,7 +217,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 // Reading the SH rows directly per lane as K1 does (only the visible rows, no input staging) was measured: 0.380 vs 0.380 ms.
 template <bool RAW>
 __global__ void __launch_bounds__(LG_PP)
-lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
+lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -231,7 +231,7 @@ lg_preprocess_bwd(int N, int M, int D, int W, int H, float tanfovx, float tanfov
 {
     __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
     const uint32_t lane = threadIdx.x;
-    const int i0 = blockIdx.x * LG_PP;
+    const int i0 = ((int)blockIdx.x + first_blk) * LG_PP;   // (chunked backward: this launch covers workgroups first_blk ...)
     const int i = i0 + (int)lane;
     float vm[16], pm[16], cp[3];
 #pragma unroll

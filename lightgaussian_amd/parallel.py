@@ -52,6 +52,94 @@ def allreduce_gradients(params, group=None, average=True, bucket_bytes=512 << 20
     return len(works)
 
 
+class OverlappedGradAllReduce:
+    """Gradient all-reduce overlapped with the backward (the data-parallel step of distill_train.py:124-166 /
+    prune_finetune.py with one camera per rank).  Inside the context every rasterizer backward runs its per-Gaussian stage
+    (K9) in `chunks` ranges of Gaussians; as soon as a range is enqueued, the rows of that range in all six gradient tensors
+    are all-reduced on a side stream -- RCCL moves range c over xGMI while K9 computes range c + 1 (and, for the first ranges,
+    while nothing else of the step is left on the device: at 6M Gaussians the 1.4 GB of gradients are ~3x the compute time of
+    a step on 8 GPUs, so hiding compute behind communication is what is left to gain).  One collective per range over ONE
+    flat staging buffer (the six row-slices packed: few, large collectives for point-to-point xGMI).
+
+        with OverlappedGradAllReduce(group, chunks=4) as ar:
+            loss.backward()
+        ar.finish(model)          # waits, averages, and installs the reduced tensors as model._xyz.grad, ...
+
+    The reduced buffers are authoritative: finish() assigns them to .grad (autograd may have stored a copy taken before the
+    collective finished).  One backward per context (one camera per rank and step, as the reference trains)."""
+
+    def __init__(self, group=None, chunks=4, average=True):
+        self.group, self.chunks, self.average = group, chunks, average
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.pending, self.grads, self.comm = [], None, None
+
+    def __enter__(self):
+        from . import rasterizer
+        rasterizer.set_grad_chunk_hook(self._on_chunk, self.chunks)
+        return self
+
+    def __exit__(self, *exc):
+        from . import rasterizer
+        rasterizer.set_grad_chunk_hook(None)
+        return False
+
+    def _on_chunk(self, first, count, grads):
+        if self.grads is not None and self.grads is not grads and first == 0:
+            raise RuntimeError("OverlappedGradAllReduce: one backward per context (use allreduce_gradients for accumulated batches)")
+        self.grads = grads
+        if not self.active or count <= 0:
+            return
+        ts = [g[first:first + count] for g in grads.values()]
+        cuda = ts[0].is_cuda
+        if cuda:
+            cur = torch.cuda.current_stream(ts[0].device)
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=ts[0].device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat, ts))
+
+    def finish(self, model=None):
+        """Wait for the collectives, scatter the reduced ranges back into the gradient tensors, average, and (when `model` is
+        given) install them as the .grad of the like-named raw parameters.  Returns the dict name -> reduced gradient."""
+        if self.grads is None:
+            return {}
+        for work, flat, ts in self.pending:
+            if self.comm is not None:
+                with torch.cuda.stream(self.comm):   # the side stream waits for the collective, then scatters the ranges back
+                    work.wait()
+                    self._unpack(flat, ts)
+            else:
+                work.wait()
+                self._unpack(flat, ts)
+        if self.comm is not None:
+            torch.cuda.current_stream(self.comm.device).wait_stream(self.comm)
+        self.pending = []
+        out = dict(self.grads)
+        if model is not None:
+            for name, g in out.items():
+                if hasattr(model, name):
+                    getattr(model, name).grad = g
+        return out
+
+    def _unpack(self, flat, ts):
+        if self.average:
+            flat.div_(self.world)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
 def make_student(teacher, sh_degree):
     """What distill_train.py:78-79 + GaussianModel.onedownSHdegree (scene/gaussian_model.py:129-136) produce: the same
     Gaussians with _features_rest cut to (sh_degree+1)^2 - 1 coefficients and active/max degree lowered."""

@@ -70,6 +70,27 @@ def set_option(name, value):
     _OPTIONS[name] = value
 
 
+_GRAD_CHUNKS = {"hook": None, "chunks": 1}
+
+
+def set_grad_chunk_hook(hook, chunks=4):
+    """hook(first, count, grads) is called from inside every rasterizer backward, once per range of Gaussians, right after the
+    K9 launch of that range is enqueued on the current stream: rows [first, first + count) of the gradient tensors in `grads`
+    (dict: parameter name -> tensor) are final from that point of the stream on.  Used by parallel.OverlappedGradAllReduce to
+    all-reduce finished ranges while K9 computes the next one.  hook=None restores the single-launch backward."""
+    _GRAD_CHUNKS["hook"] = hook
+    _GRAD_CHUNKS["chunks"] = max(1, int(chunks)) if hook is not None else 1
+
+
+def _call_backward(lib, args, grads_by_name):
+    """lg_backward, or lg_backward_chunked when a gradient-chunk hook is installed."""
+    hook = _GRAD_CHUNKS["hook"]
+    if hook is None:
+        return lib.lg_backward(*args)
+    cb = _lib.CHUNK_FN(lambda _user, first, count: hook(int(first), int(count), grads_by_name))
+    return lib.lg_backward_chunked(*args, int(_GRAD_CHUNKS["chunks"]), cb, None)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -302,10 +323,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_rot = torch.empty((N, 4), **f32) if call.rots is not None else None
             g_cov = torch.empty((N, 6), **f32) if call.cov is not None else None
             scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
-            rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
-                                 C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
-                                 _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov), None,
-                                 _ptr(scratch), stream)
+            rc = _call_backward(lib, (C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                      C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
+                                      _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov), None,
+                                      _ptr(scratch), stream),
+                                {k: v for k, v in (("means3D", g_means3D), ("shs", g_sh), ("colors_precomp", g_col), ("opacities", g_opac),
+                                                   ("scales", g_sc), ("rotations", g_rot), ("cov3D_precomp", g_cov)) if v is not None})
             _lib.check(rc)
         had_sh, had_col, had_sc, had_cov = ctx.had
         return (g_means3D, g_means2D, g_sh if had_sh else None, g_col if had_col else None, g_opac,
@@ -352,9 +375,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_rest = torch.empty((N, rest.shape[1], 3), **f32) if rest is not None else None
             g_sc = torch.empty((N, 3), **f32); g_rot = torch.empty((N, 4), **f32)
             scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
-            rc = lib.lg_backward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
-                                 C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_xyz), _ptr(g_dc), None,
-                                 _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), None, _ptr(g_rest), _ptr(scratch), stream)
+            rc = _call_backward(lib, (C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                      C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_xyz), _ptr(g_dc), None,
+                                      _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), None, _ptr(g_rest), _ptr(scratch), stream),
+                                {k: v for k, v in (("_xyz", g_xyz), ("_features_dc", g_dc), ("_features_rest", g_rest), ("_opacity", g_opac),
+                                                   ("_scaling", g_sc), ("_rotation", g_rot)) if v is not None})
             _lib.check(rc)
         if g_rest is None and ctx.rest_shape is not None:
             g_rest = torch.zeros(ctx.rest_shape, **f32)

@@ -50,3 +50,41 @@ def test_shard_views_and_student():
     s = parallel.make_student(t, 2)
     assert s._features_rest.shape == (50, 8, 3) and s.active_sh_degree == 2 and s.get_features.shape == (50, 9, 3)
     assert torch.equal(s._features_rest, t._features_rest[:, :8])
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lightgaussian_amd import rasterizer
+        g = torch.Generator().manual_seed(200 + rank)
+        n = 1000
+        grads = {"_xyz": torch.randn(n, 3, generator=g), "_features_rest": torch.randn(n, 15, 3, generator=g), "_opacity": torch.randn(n, 1, generator=g)}
+        model = type("M", (), {})()
+        for k in grads:
+            setattr(model, k, torch.zeros_like(grads[k]).requires_grad_(True))
+        with parallel.OverlappedGradAllReduce(chunks=4) as ar:
+            hook = rasterizer._GRAD_CHUNKS["hook"]
+            assert hook is not None and rasterizer._GRAD_CHUNKS["chunks"] == 4
+            for first in range(0, n, 256):                       # what lg_backward_chunked reports: ranges of whole workgroups
+                hook(first, min(256, n - first), grads)
+        assert rasterizer._GRAD_CHUNKS["hook"] is None
+        out = ar.finish(model)
+        assert out["_xyz"] is grads["_xyz"] and model._xyz.grad is grads["_xyz"]
+        np.savez(os.path.join(out_dir, f"o{rank}.npz"), **{k: v.numpy() for k, v in grads.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_of_gradient_ranges(tmp_path):
+    """The host logic of the overlapped data-parallel step: every Gaussian range reported by the chunked backward is
+    all-reduced (one packed collective per range) and scattered back; finish() installs the averaged tensors as .grad."""
+    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(tmp_path / f"o{r}.npz") for r in range(2)]
+    gens = [torch.Generator().manual_seed(200 + r) for r in range(2)]
+    per_rank = [{k: torch.randn(s, generator=gens[r]) for k, s in (("_xyz", (1000, 3)), ("_features_rest", (1000, 15, 3)), ("_opacity", (1000, 1)))}
+                for r in range(2)]
+    for k in ("_xyz", "_features_rest", "_opacity"):
+        mean = ((per_rank[0][k] + per_rank[1][k]) / 2).numpy()
+        for o in outs:
+            assert np.allclose(o[k], mean, rtol=1e-6, atol=1e-7), k
