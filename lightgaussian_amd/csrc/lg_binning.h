@@ -27,29 +27,34 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t m = 0, f = 0;
     uint64_t carry = 0;                          // instances before this round (64-bit: an overflow past 2^32 must be seen)
+    const int last4 = (nblk - 1) & ~3;          // start of the last aligned group of four words (the arrays are padded past it)
     for (int round0 = 0; round0 < nblk; round0 += 65536) {
         const int i0 = round0 + (int)tid * 64;
+        // every load is issued unconditionally from a clamped (always in-bounds) address and masked afterwards: no branch sits
+        // between the sixteen loads of a thread, so they are all in flight together
+        {
+            uint4 d[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) d[q] = *reinterpret_cast<const uint4*>(blk_dmax + min(i0 + 4 * q, last4));
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int i = i0 + 4 * q;
+                const uint32_t dx = (i < nblk) ? d[q].x : 0u, dy = (i + 1 < nblk) ? d[q].y : 0u, dz = (i + 2 < nblk) ? d[q].z : 0u,
+                               dw = (i + 3 < nblk) ? d[q].w : 0u;
+                m = max(max(m, dx & 0x7FFFFFFFu), max(dy & 0x7FFFFFFFu, max(dz & 0x7FFFFFFFu, dw & 0x7FFFFFFFu)));
+                f |= (dx | dy | dz | dw) >> 31;
+            }
+        }
+        asm volatile("" ::: "memory");           // keep the second batch of loads behind the first batch's reduction (register pressure)
         uint4 v[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = i0 + 4 * q;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (i < nblk) v[q] = *reinterpret_cast<const uint4*>(blk_sum + i);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = i0 + 4 * q;
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (i < nblk) d = *reinterpret_cast<const uint4*>(blk_dmax + i);
-            d.y = (i + 1 < nblk) ? d.y : 0u; d.z = (i + 2 < nblk) ? d.z : 0u; d.w = (i + 3 < nblk) ? d.w : 0u;
-            m = max(max(m, d.x & 0x7FFFFFFFu), max(d.y & 0x7FFFFFFFu, max(d.z & 0x7FFFFFFFu, d.w & 0x7FFFFFFFu)));
-            f |= (d.x | d.y | d.z | d.w) >> 31;
-        }
+        for (int q = 0; q < 16; q++) v[q] = *reinterpret_cast<const uint4*>(blk_sum + min(i0 + 4 * q, last4));
         uint32_t sum = 0;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int i = i0 + 4 * q;
-            v[q].y = (i + 1 < nblk) ? v[q].y : 0u; v[q].z = (i + 2 < nblk) ? v[q].z : 0u; v[q].w = (i + 3 < nblk) ? v[q].w : 0u;
+            v[q].x = (i < nblk) ? v[q].x : 0u; v[q].y = (i + 1 < nblk) ? v[q].y : 0u;
+            v[q].z = (i + 2 < nblk) ? v[q].z : 0u; v[q].w = (i + 3 < nblk) ? v[q].w : 0u;
             sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
         }
         uint32_t inc = sum;
@@ -75,12 +80,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
             uint4 o;
             o.x = run; o.y = run + v[q].x; o.z = o.y + v[q].y; o.w = o.z + v[q].z;
             run = o.w + v[q].w;
-            if (i + 3 < nblk) *reinterpret_cast<uint4*>(blk_off + i) = o;
-            else {
-                if (i < nblk) blk_off[i] = o.x;
-                if (i + 1 < nblk) blk_off[i + 1] = o.y;
-                if (i + 2 < nblk) blk_off[i + 2] = o.z;
-            }
+            if (i <= last4) *reinterpret_cast<uint4*>(blk_off + i) = o;   // (the padded tail of blk_off takes the words past nblk)
         }
         carry += total;
         __syncthreads();

@@ -1,0 +1,90 @@
+"""-m gpu: the chunked backward (lg_backward_chunked) and the gradient all-reduce overlapped with it
+(parallel.OverlappedGradAllReduce) -- chunking must not change a single bit of the gradients, every
+Gaussian range must be reported exactly once and in order, and through RCCL (backend nccl, world size 1: the real collective
+code path on device tensors) the reduced gradients equal the plain backward's."""
+import math
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import common
+from common import syn
+from lightgaussian_amd import parallel, rasterizer
+from lightgaussian_amd.gaussian_renderer import render
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+NAMES = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+
+def _setup(N=10_007):
+    g = syn.make_gaussians(N, seed=23, log_scale_mean=math.log(0.04)).to(DEV)
+    cam = syn.orbit_camera(2, 9, 240, 160).to(DEV)
+    gimg = torch.randn(3, 160, 240, generator=torch.Generator().manual_seed(5)).to(DEV)
+    return g, cam, syn.PipelineParams(), torch.tensor([0.2, 0.1, 0.0], device=DEV), gimg
+
+
+def _model(g):
+    return syn.SyntheticGaussians(*[getattr(g, n).detach().clone().requires_grad_(True) for n in
+                                    ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")], 3, 3)
+
+
+def _grads(pc):
+    return {n: getattr(pc, n).grad.clone() for n in NAMES}
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 4, 1000])
+def test_chunked_backward_is_bit_identical_and_reports_every_range_once(chunks):
+    g, cam, pipe, bg, gimg = _setup()
+    pc = _model(g)
+    (render(cam, pc, pipe, bg)["render"] * gimg).sum().backward()
+    ref = _grads(pc)
+    seen = []
+    rasterizer.set_grad_chunk_hook(lambda first, count, grads: seen.append((first, count, tuple(sorted(grads)))), chunks)
+    try:
+        pc2 = _model(g)
+        (render(cam, pc2, pipe, bg)["render"] * gimg).sum().backward()
+    finally:
+        rasterizer.set_grad_chunk_hook(None)
+    for n in NAMES:
+        assert torch.equal(ref[n], getattr(pc2, n).grad), n
+    N = g.num
+    nblk = (N + 63) // 64
+    assert 1 <= len(seen) <= min(chunks, nblk) and (chunks == 1) == (len(seen) == 1)
+    pos = 0
+    for first, count, names in seen:
+        assert first == pos and first % 64 == 0 and count > 0
+        assert names == tuple(sorted(NAMES))
+        pos += count
+    assert pos == N
+
+
+def test_overlapped_gradient_allreduce_through_rccl():
+    g, cam, pipe, bg, gimg = _setup(N=30_000)
+    pc = _model(g)
+    (render(cam, pc, pipe, bg)["render"] * gimg).sum().backward()
+    ref = _grads(pc)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=DEV)
+    try:
+        pc2 = _model(g)
+        loss = (render(cam, pc2, pipe, bg)["render"] * gimg).sum()
+        with parallel.OverlappedGradAllReduce(chunks=4) as ar:
+            loss.backward()
+        assert len(ar.pending) == 4
+        out = ar.finish(pc2)
+        torch.cuda.synchronize()
+        assert set(out) == set(NAMES)
+        for n in NAMES:
+            assert getattr(pc2, n).grad is out[n]
+            assert torch.equal(out[n], ref[n]), n                # world size 1: sum / 1
+        # the blocking bucketed form gives the same
+        pc3 = _model(g)
+        (render(cam, pc3, pipe, bg)["render"] * gimg).sum().backward()
+        parallel.allreduce_gradients([getattr(pc3, n) for n in NAMES])
+        for n in NAMES:
+            assert torch.equal(getattr(pc3, n).grad, ref[n]), n
+    finally:
+        dist.destroy_process_group()
