@@ -39,6 +39,7 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
     if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
     if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
     if (g->N == 0) return LG_OK; // nothing to validate against: empty tensors carry no pointers
+    if (g->N >= (1 << LG_ID_BITS)) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^29-1 Gaussians (the blend record packs the id in 29 bits)");
     if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
         return fail(LG_ERR_INVALID_ARGUMENT, "Please provide excatly one of either SHs or precomputed colors!");
     const bool sr = g->scales != nullptr && g->rotations != nullptr;
@@ -99,7 +100,9 @@ struct PinnedSlot {
 
 // Layout of the sort key of one view: tile | (depth bits - bias) | Gaussian id.  Exact forward: from the read-back depth
 // maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
+#ifndef LG_MIN_DEPTH_BITS
 #define LG_MIN_DEPTH_BITS 18
+#endif
 struct KeyPlan { bool packed; int tile_bits, gid_bits, depth_bits, drop; uint32_t gid_mask; };
 static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t flags)
 {
@@ -390,7 +393,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
 #define LAUNCH_PPB(RAWP)                                                                                                             \
     lg_preprocess_bwd<RAWP><<<nb, LG_PP, 0, stream>>>(                                                                                \
         N, first_blk, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
-        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec, geo.aux,   \
+        g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec,   \
         geo.counters, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
             if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);

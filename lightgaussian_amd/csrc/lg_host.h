@@ -78,8 +78,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 #endif
 
 struct GeomView {
-    float4* rec;        // [N][LG_REC_F4]  blend record {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id-bits}
-    float4* aux;        // [N][2]  backward record {cov3D[0..3]} {cov3D[4], cov3D[5], clamp-bits, -}
+    float4* rec;        // [N][LG_REC_F4]  blend record {x, y, ha, nb} {hc, opacity, r, g} {b, hx, hy, id | SH clamp flags << 29}
     uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
     uint32_t* touched;  // [N]  instance count per Gaussian (K1)
     uint32_t* offsets;  // [N]  inclusive scan of touched (written by K3; K9 derives the slot base from it)
@@ -99,7 +98,6 @@ static GeomView carve_geom(void* base, int N)
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     size_t n = (size_t)(N > 0 ? N : 1);
     g.rec = (float4*)take(n * 16 * LG_REC_F4);
-    g.aux = (float4*)take(n * 32);
     g.tinfo = (uint4*)take(n * 16);
     g.touched = (uint32_t*)take(n * 4);
     g.offsets = (uint32_t*)take(n * 4);

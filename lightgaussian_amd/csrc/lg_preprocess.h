@@ -10,6 +10,8 @@
 // bytes, contiguous in memory) are fetched with coalesced 16-byte loads into LDS -- skipping rows of
 // culled Gaussians -- instead of 48 strided dword loads per lane.
 #define LG_PP 64
+#define LG_ID_BITS 29            // blend record, last word: Gaussian id | SH clamp flags << 29
+#define LG_ID_MASK ((1u << LG_ID_BITS) - 1u)
 #define LG_SH_MAXF 48 // floats per SH row at M = 16
 #define LG_COOP_ROWS 48u // K9: splats with more tile instances than this are gathered by the whole wave
 
@@ -77,7 +79,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     // allocated for SH (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3).  The LDS-staged
     // variant is kept behind the LG_K1_LDS environment switch as the cross-check of the direct reads.
     __shared__ __attribute__((aligned(16))) float sh_rows[DIRECT ? 4 : LG_PP * LG_SH_MAXF];
-    __shared__ float4 st_rec[LG_PP * 3], st_aux[LG_PP * 2]; // records leave through LDS as coalesced 16-byte stores
+    __shared__ float4 st_rec[LG_PP * 3]; // records leave through LDS as coalesced 16-byte stores
     static_assert(LG_REC_F4 == 3, "coalesced record store assumes packed 48-byte records");
     const uint32_t lane = threadIdx.x;
     const int i0 = blockIdx.x * LG_PP;
@@ -167,16 +169,16 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
             }
             st_rec[3 * lane + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
             st_rec[3 * lane + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
-            st_rec[3 * lane + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i));
-            st_aux[2 * lane + 0] = make_float4(cov[0], cov[1], cov[2], cov[3]);
-            st_aux[2 * lane + 1] = make_float4(cov[4], cov[5], __uint_as_float(cb), 0.0f);
+            // last word: Gaussian id (29 bits) | SH clamp flags (3 bits, for K9).  No separate "backward record": K9 recomputes the
+            // 3D covariance from the scales / rotation it reads anyway (the 32-byte aux rows of round 1 were 10 % of K1's traffic)
+            st_rec[3 * lane + 2] = make_float4(rgb[2], sp.hx, sp.hy, __uint_as_float((uint32_t)i | (cb << LG_ID_BITS)));
             g.tinfo[i] = make_uint4((uint32_t)sp.tx0 | ((uint32_t)sp.ty0 << 16), (uint32_t)sp.tx1 | ((uint32_t)sp.ty1 << 16),
                                     __float_as_uint(sp.depth), 0u);
         }
         radii[i] = radius;
         g.touched[i] = touched;
     }
-    // The records of the workgroup's 64 Gaussians are contiguous in rec / aux: staged in LDS and written as coalesced
+    // The records of the workgroup's 64 Gaussians are contiguous in rec: staged in LDS and written as coalesced
     // 16-byte stores (per-lane 48-byte-stride stores measured 0.26 -> 0.22 ms for the whole kernel).  Entries of
     // invisible Gaussians carry stale LDS contents; nothing reads them (touched == 0).
     if (vmask) {
@@ -187,9 +189,6 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 #pragma unroll
         for (int k = 0; k < 3; k++)
             if ((int)(k * LG_PP + lane) < 3 * nrec) g.rec[3 * (size_t)i0 + k * LG_PP + lane] = st_rec[k * LG_PP + lane];
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if ((int)(k * LG_PP + lane) < 2 * nrec) g.aux[2 * (size_t)i0 + k * LG_PP + lane] = st_aux[k * LG_PP + lane];
     }
     // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
     // largest depth of the workgroup (bit pattern; positive floats order like integers), for the packed sort key.
@@ -222,7 +221,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                  const int32_t* __restrict__ radii, const float4* __restrict__ rec, const float4* __restrict__ aux,
+                  const int32_t* __restrict__ radii, const float4* __restrict__ rec,
                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ touched,
                   const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
@@ -296,12 +295,27 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
         }
         // the rows are pixel-offset moments (lg_blend.h): finish them with this Gaussian's conic and opacity, exactly the
         // values the blend kernels used (its blend record)
-        const float4 q0 = rec[LG_REC_F4 * (size_t)i], q1 = rec[LG_REC_F4 * (size_t)i + 1];
+        const float4 q0 = rec[LG_REC_F4 * (size_t)i], q1 = rec[LG_REC_F4 * (size_t)i + 1], q2 = rec[LG_REC_F4 * (size_t)i + 2];
         float a[9];
         lg_rows_to_grads(mo, q0.z, q0.w, q1.x, q1.y, a);
         const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
-        const float4 x0 = aux[2 * (size_t)i], x1 = aux[2 * (size_t)i + 1];
-        float S[6] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y };
+        // 3D covariance: the precomputed input, or recomputed from the (activated) scales / rotation exactly as K1 did
+        float S[6], sc[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0}, qn = 1.0f;
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) S[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            sc[0] = scales[3 * (size_t)i]; sc[1] = scales[3 * (size_t)i + 1]; sc[2] = scales[3 * (size_t)i + 2];
+            const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+            q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            if (RAW) {
+                sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+                const float inv = 1.0f / qn;
+                q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+            }
+            lg_cov3d(sc, mod, q, S);
+        }
         LgGradOut go;
         lg_backward_geom(vm, pm, px, py, pz, S, a, W, H, tanfovx, tanfovy, go);
         m2[0] = go.mean2D[0]; m2[1] = go.mean2D[1];
@@ -310,7 +324,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
         if (colors_precomp) {
             dcol[0] = a[6]; dcol[1] = a[7]; dcol[2] = a[8];
         } else if (use_sh) {
-            const uint32_t cb = __float_as_uint(x1.z);
+            const uint32_t cb = __float_as_uint(q2.w) >> LG_ID_BITS;
             float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
             float sh[LG_SH_MAXF];
             const float* row = sh_rows + lane * rowf;
@@ -336,16 +350,6 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
 #pragma unroll
             for (int k = 0; k < 6; k++) dcov[k] = go.cov3D[k];
         } else {
-            float sc[3] = { scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2] };
-            const float4 q4 = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
-            float q[4] = { q4.x, q4.y, q4.z, q4.w };
-            float qn = 1.0f;
-            if (RAW) {
-                sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-                qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
-                const float inv = 1.0f / qn;
-                q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
-            }
             lg_backward_cov3d(sc, mod, q, go.cov3D, dsc, drot);
             if (RAW) {
                 // exp: d/draw = d/ds * s ; normalize: d/dr = (g - q (q.g)) / |r|

@@ -41,7 +41,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # process-wide knobs that are not part of the reference API
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
-            "fuse_getters": True, "sync_free": False, "max_depth": 100.0, "capacity_margin": 1.25}
+            "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25}
 
 
 def set_option(name, value):
@@ -55,7 +55,7 @@ def set_option(name, value):
               uninitialised memory); for passes that only consume gaussians_count / important_score, e.g. prune_list_sharded;
     sync_free: False = every forward takes the exact path (lg_forward: the device idles while the host reads the instance
               count, allocates and launches the rest, as in the reference extension).
-              "validated" = lg_forward_bounded with host status: the whole view is enqueued against a capacity learnt from
+              "validated" (default) = lg_forward_bounded with host status: the whole view is enqueued against a capacity learnt from
               earlier views of the same shape, then the host waits for the status words that left behind K2 -- same
               guarantees as the exact path (an overflowing view is re-run at once, transparently), no idle device.
               True = nothing is read back at all, so one host thread can keep several views in flight on several streams.  The binning buffer is sized capacity_margin x the
@@ -181,8 +181,8 @@ def pending_status():
         out.append(flags != 0)
         with _CAP_LOCK:
             if flags & 2:
-                _CAPACITY.pop(key, None)           # depth bound violated: this shape goes back to the exact path
-            elif flags or key in _CAPACITY:
+                _CAPACITY[key] = -1                # depth bound violated: this shape goes back to the exact path
+            elif (flags or key in _CAPACITY) and _CAPACITY.get(key, 0) >= 0:
                 _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * _OPTIONS["capacity_margin"]) + 4096)
     return out
 
@@ -195,7 +195,8 @@ def pending_overflow():
 def _note_count(key, R):
     with _CAP_LOCK:
         want = int(R * _OPTIONS["capacity_margin"]) + 4096
-        if want > _CAPACITY.get(key, 0):
+        have = _CAPACITY.get(key, 0)
+        if have >= 0 and want > have:
             _CAPACITY[key] = want
 
 
@@ -216,7 +217,7 @@ def _native_forward(lib, call, rs, count):
     key = (dev.index, N, W, H)
     mode = _OPTIONS["sync_free"]
     cap = _CAPACITY.get(key) if (mode and N > 0 and not rs.prefiltered) else None
-    if cap is not None:
+    if cap is not None and cap > 0:          # (-1: a depth beyond max_depth was seen for this shape -> exact path for good)
         binning = torch.empty(lib.lg_binning_bytes(cap, W, H), **u8)
         if mode == "validated":
             # everything of the view is enqueued, then the host waits for the four status words that left right behind K2:
@@ -231,7 +232,7 @@ def _native_forward(lib, call, rs, count):
                 return color, radii, gcount, score, geom, binning, img, cap
             with _CAP_LOCK:                        # the view did not fit (its kernels were no-ops): exact path below, same buffers
                 if host[0] & 2:
-                    _CAPACITY.pop(key, None)
+                    _CAPACITY[key] = -1
                 else:
                     _CAPACITY[key] = int(int(host[3]) * _OPTIONS["capacity_margin"]) + 4096
             del binning

@@ -18,8 +18,10 @@ DEV = torch.device("cuda:0")
 
 @pytest.fixture(autouse=True)
 def _restore_options():
+    rasterizer.set_option("sync_free", False)      # the tests below choose the mode explicitly
+    rasterizer._CAPACITY.clear()
     yield
-    rasterizer.set_option("sync_free", False)
+    rasterizer.set_option("sync_free", "validated")
     rasterizer.set_option("max_depth", 100.0)
     rasterizer.pending_status()
     rasterizer._CAPACITY.clear()
@@ -92,10 +94,11 @@ def test_overflow_is_reported_on_the_device_and_the_view_contributes_zeros():
         # a depth beyond max_depth: reported too, and the shape goes back to the exact path
         rasterizer.set_option("max_depth", 1.0)
         out = count_render(cams[1], g, pipe, bg)
-        assert rasterizer.pending_status() == [True] and key not in rasterizer._CAPACITY
+        assert rasterizer.pending_status() == [True] and rasterizer._CAPACITY[key] == -1   # this shape stays on the exact path
     # backward through an abandoned view: zero gradients, no out-of-bounds reads
     rasterizer.set_option("max_depth", 100.0)
     rasterizer._CAPACITY[key] = 1000
+    rasterizer.set_option("sync_free", True)
     pc = syn.SyntheticGaussians(*[t.detach().clone().requires_grad_(True) for t in
                                   (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)], 3, 3)
     pkg = render(cams[1], pc, pipe, bg)
