@@ -188,8 +188,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             // K2: one workgroup scans the per-K1-workgroup instance counts and reduces the depth maxima (replaces a
             // device-wide scan of N words + a separate reduction kernel)
             ProfScope ps(prof, "scan", stream);
-            lg_scan_blocks<<<1, 1024, 0, stream>>>(nblk, geo.blk_sum, geo.blk_dmax, geo.blk_off, bounded ? (uint32_t)cap : 0xFFFFFFFFu,
-                                                   bounded ? kp.depth_bits : 32, geo.counters);
+            lg_scan_blocks<<<(nblk + LG_PART - 1) / LG_PART, LG_PART, 0, stream>>>(nblk, geo.blk_sum, geo.blk_dmax, geo.blk_off, geo.part_sum,
+                                                                                  geo.part_dmax, geo.part_prefix, geo.counters + 8,
+                                                                                  bounded ? (uint32_t)cap : 0xFFFFFFFFu,
+                                                                                  bounded ? kp.depth_bits : 32, geo.counters);
         }
         KCHECK("lg_scan_blocks");
     }
@@ -247,9 +249,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), 256));
             if (kp.packed)
                 lg_duplicate<true><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
-                                                              geo.blk_off, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);
+                                                              geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);
             else
-                lg_duplicate<false><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.counters, geo.offsets,
+                lg_duplicate<false><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.part_prefix, geo.counters, geo.offsets,
                                                                geo.tinfo, bin.keys_in, bin.vals_in, ntiles, bin.ranges, nullptr);
         }
         KCHECK("lg_duplicate");

@@ -6,63 +6,77 @@
 #include "lg_wave.h"
 
 // ------------------------------------------------------------------------------------------------
-// K2: exclusive scan of the per-workgroup instance counts of K1 (one word per 64 Gaussians) by ONE workgroup, fused with
-// the reduction of the per-workgroup depth maxima / prefiltered flags.  counters[0..3] (every word written: no memset):
+// K2: exclusive scan of the per-workgroup instance counts of K1 (one word per 64 Gaussians), fused with the reduction of the
+// per-workgroup depth maxima / prefiltered flags.  counters[0..3] (every word written: no memset):
 //   [0] abort flags of the view: bit 0 = more instances than `capacity`, bit 1 = a depth beyond the `depth_bits` the keys
 //       were laid out for (both can only fire in the capacity-bounded forward, whose host side knows neither number);
 //       every later kernel of the view returns at once when [0] != 0
 //   [1] any prefiltered violation (bit 31 of the per-workgroup words)   [2] largest depth bit pattern   [3] R
+// Two levels in ONE launch: workgroup p scans words [1024 p, 1024 p + 1024) (blk_off = exclusive prefix INSIDE the part) and
+// publishes the part's total / depth maximum; the workgroup that arrives last (one agent-scope atomic per workgroup, 46 at
+// C3) scans the part totals into part_prefix and writes the counters.  Consumers add part_prefix[b >> 10] to blk_off[b].
+// (Two single-workgroup versions of this kernel -- a load per iteration, then all loads in flight from registers -- both
+// measured 50 us at C3: a lone workgroup on an otherwise idle device is slow whatever it does; so are the 10 us of
+// lg_work_order's 8160 tiles.  46 workgroups finish the same work in a few microseconds.)
 #define LG_DEPTH_BIAS (124u << 23) // bit pattern of 0.125f < the 0.2 near plane
-// One workgroup, ONE memory round trip per 65 536 words: thread t owns 64 consecutive words of a round and fetches them with
-// sixteen 16-byte loads that are all in flight together (fully unrolled, no branch between them), keeps them in registers,
-// block-scans the per-thread sums through LDS and writes the exclusive prefixes from the registers.  (A loop with a load per
-// iteration serialises on memory latency: 40 us at C3 for 47 k words, as much as the hipCUB scan + reduction it replaced.)
-// The arrays are 256-byte aligned and padded (carve_geom), so an aligned 16-byte load that straddles the end is in bounds;
-// the words past nblk are masked.
-__global__ void __launch_bounds__(1024)
+#define LG_PART 1024               // words per part = threads per workgroup
+
+__global__ void __launch_bounds__(LG_PART)
 lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ blk_off,
-               uint32_t capacity, int depth_bits, uint32_t* __restrict__ counters)
+               uint32_t* part_sum, uint32_t* part_dmax, uint32_t* __restrict__ part_prefix, uint32_t* done, uint32_t capacity,
+               int depth_bits, uint32_t* __restrict__ counters)
 {
     __shared__ uint32_t wsum[16], wmax[16], wflag[16];
+    __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t m = 0, f = 0;
-    uint64_t carry = 0;                          // instances before this round (64-bit: an overflow past 2^32 must be seen)
-    const int last4 = (nblk - 1) & ~3;          // start of the last aligned group of four words (the arrays are padded past it)
-    for (int round0 = 0; round0 < nblk; round0 += 65536) {
-        const int i0 = round0 + (int)tid * 64;
-        // every load is issued unconditionally from a clamped (always in-bounds) address and masked afterwards: no branch sits
-        // between the sixteen loads of a thread, so they are all in flight together
-        {
-            uint4 d[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) d[q] = *reinterpret_cast<const uint4*>(blk_dmax + min(i0 + 4 * q, last4));
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int i = i0 + 4 * q;
-                const uint32_t dx = (i < nblk) ? d[q].x : 0u, dy = (i + 1 < nblk) ? d[q].y : 0u, dz = (i + 2 < nblk) ? d[q].z : 0u,
-                               dw = (i + 3 < nblk) ? d[q].w : 0u;
-                m = max(max(m, dx & 0x7FFFFFFFu), max(dy & 0x7FFFFFFFu, max(dz & 0x7FFFFFFFu, dw & 0x7FFFFFFFu)));
-                f |= (dx | dy | dz | dw) >> 31;
-            }
-        }
-        asm volatile("" ::: "memory");           // keep the second batch of loads behind the first batch's reduction (register pressure)
-        uint4 v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = *reinterpret_cast<const uint4*>(blk_sum + min(i0 + 4 * q, last4));
-        uint32_t sum = 0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = i0 + 4 * q;
-            v[q].x = (i < nblk) ? v[q].x : 0u; v[q].y = (i + 1 < nblk) ? v[q].y : 0u;
-            v[q].z = (i + 2 < nblk) ? v[q].z : 0u; v[q].w = (i + 3 < nblk) ? v[q].w : 0u;
-            sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
-        }
-        uint32_t inc = sum;
+    const int nparts = (int)gridDim.x;
+    {
+        const int i = (int)blockIdx.x * LG_PART + (int)tid;
+        const uint32_t v = i < nblk ? blk_sum[i] : 0u, d = i < nblk ? blk_dmax[i] : 0u;
+        uint32_t inc = v, m = d & 0x7FFFFFFFu, f = d >> 31;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const uint32_t o = __shfl_up(inc, s, 64);
             if ((int)lane >= s) inc += o;
         }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
+        if (lane == 63u) { wsum[wave] = inc; wmax[wave] = m; wflag[wave] = f; }
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            woff += (w < (int)wave) ? t : 0u;
+            total += t;
+            m = max(m, wmax[w]); f |= wflag[w];
+        }
+        if (i < nblk) blk_off[i] = woff + inc - v;
+        if (tid == 0) {
+            __hip_atomic_store(&part_sum[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part_dmax[blockIdx.x], m | (f << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();                                        // the two words above before the arrival below
+            s_last = (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nparts - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_last) return;
+    }
+    // ---- last workgroup to arrive: scan the part totals (64-bit running sum: an overflow past 2^32 must be seen) ----
+    __threadfence();
+    uint32_t m = 0, f = 0;
+    uint64_t carry = 0;
+    for (int base = 0; base < nparts; base += LG_PART) {
+        const int j = base + (int)tid;
+        const uint32_t v = j < nparts ? __hip_atomic_load(&part_sum[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t d = j < nparts ? __hip_atomic_load(&part_dmax[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        m = max(m, d & 0x7FFFFFFFu); f |= d >> 31;
+        uint32_t inc = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(inc, s, 64);
+            if ((int)lane >= s) inc += o;
+        }
+        __syncthreads();                                            // (wsum of the previous round / of the part scan is free)
         if (lane == 63u) wsum[wave] = inc;
         __syncthreads();
         uint32_t woff = 0;
@@ -73,20 +87,12 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
             woff += (w < (int)wave) ? t : 0u;
             total += t;
         }
-        uint32_t run = (uint32_t)carry + woff + inc - sum;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = i0 + 4 * q;
-            uint4 o;
-            o.x = run; o.y = run + v[q].x; o.z = o.y + v[q].y; o.w = o.z + v[q].z;
-            run = o.w + v[q].w;
-            if (i <= last4) *reinterpret_cast<uint4*>(blk_off + i) = o;   // (the padded tail of blk_off takes the words past nblk)
-        }
+        if (j < nparts) part_prefix[j] = (uint32_t)carry + woff + inc - v;
         carry += total;
-        __syncthreads();
     }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, sh)); f |= (uint32_t)__shfl_xor((int)f, sh); }
+    __syncthreads();
     if (lane == 0u) { wmax[wave] = m; wflag[wave] = f; }
     __syncthreads();
     if (tid == 0) {
@@ -99,6 +105,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
         counters[1] = f;
         counters[2] = m;
         counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
+        *done = 0u;                                                 // ready for the next view that reuses this buffer
     }
 }
 
@@ -122,7 +129,8 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 template <bool PACKED>
 __global__ void __launch_bounds__(LG_DUP_THREADS)
 lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
-             const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ counters,
+             const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ part_prefix,
+             const uint32_t* __restrict__ counters,
              uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
              int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
 {
@@ -149,7 +157,7 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
         for (int u = 0; u < 4; u++) {
             const int b = g * 4 + u, i = b * 64 + (int)lane;
             t4[u] = (b < nblk && i < N) ? touched[i] : 0u;
-            base4[u] = b < nblk ? blk_off[b] : 0u;
+            base4[u] = b < nblk ? blk_off[b] + part_prefix[b / LG_PART] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {

@@ -83,10 +83,12 @@ struct GeomView {
     uint32_t* touched;  // [N]  instance count per Gaussian (K1)
     uint32_t* offsets;  // [N]  inclusive scan of touched (written by K3; K9 derives the slot base from it)
     uint32_t* counters; // [16] per-view device words: 0 = abort flags, 1 = prefiltered violation, 2 = largest depth bit
-                        //      pattern, 3 = instance count R (all written by lg_scan_blocks)
+                        //      pattern, 3 = instance count R (all written by lg_scan_blocks); 8 = arrival counter of
+                        //      lg_scan_blocks (zeroed by K1, left at zero by the scan)
     uint32_t* blk_dmax; // [ceil(N/64)] per-K1-workgroup largest depth bit pattern (bit 31: prefiltered violation)
     uint32_t* blk_sum;  // [ceil(N/64)] per-K1-workgroup instance count
-    uint32_t* blk_off;  // [ceil(N/64)] its exclusive scan (lg_scan_blocks)
+    uint32_t* blk_off;  // [ceil(N/64)] its exclusive scan inside each part of 1024 words (lg_scan_blocks)
+    uint32_t *part_sum, *part_dmax, *part_prefix;   // [ceil(N/65536)] per part: instance count, depth maximum, exclusive scan
     size_t total;
 };
 
@@ -105,6 +107,9 @@ static GeomView carve_geom(void* base, int N)
     g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
     g.blk_sum = (uint32_t*)take(((n + 63) / 64) * 4);
     g.blk_off = (uint32_t*)take(((n + 63) / 64) * 4);
+    g.part_sum = (uint32_t*)take(((n + 65535) / 65536) * 4);
+    g.part_dmax = (uint32_t*)take(((n + 65535) / 65536) * 4);
+    g.part_prefix = (uint32_t*)take(((n + 65535) / 65536) * 4);
     g.total = off;
     return g;
 }

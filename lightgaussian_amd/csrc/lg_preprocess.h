@@ -205,6 +205,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     if (lane == 0) {
         g.blk_dmax[blockIdx.x] = dmax | (any_violation ? 0x80000000u : 0u);
         g.blk_sum[blockIdx.x] = tsum;
+        if (blockIdx.x == 0) g.counters[8] = 0u;   // arrival counter of lg_scan_blocks (the scratch buffer arrives uninitialised)
     }
 }
 
