@@ -33,7 +33,7 @@
 #define LG_SORT_TILE (LG_SORT_BLOCK * LG_SORT_ITEMS)
 #define LG_SORT_MAX_PASSES 8 // 64 key bits / 8
 #ifndef LG_SORT_WINDOW
-#define LG_SORT_WINDOW 16    // predecessors examined per look-back round trip
+#define LG_SORT_WINDOW 4     // predecessors examined per look-back round trip (16 cost 26 more VGPRs: one tile per CU instead of two)
 #endif
 #define LG_SORT_FLAG_AGG 1u
 #define LG_SORT_FLAG_PREFIX 2u
@@ -95,7 +95,13 @@ __device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { (void)__h
 // One digit pass.  counters (may be NULL): [0] != 0 aborts the view (capacity overflow, lg_forward_bounded), [3] = key
 // count; with counters == NULL the count is n_arg.  hist = this pass's 256 global digit counts, ticket / states = this
 // pass's ticket word and state array (zeroed by the caller's one memset).
-__global__ void __launch_bounds__(LG_SORT_BLOCK)
+// (two 1024-thread tiles per CU need 8 waves per SIMD, i.e. at most 64 VGPRs: requested explicitly)
+#ifdef LG_SORT_NO_FORCE
+#define LG_SORT_OCC
+#else
+#define LG_SORT_OCC __attribute__((amdgpu_waves_per_eu(LG_SORT_BLOCK / 128, LG_SORT_BLOCK / 128)))
+#endif
+__global__ void __launch_bounds__(LG_SORT_BLOCK) LG_SORT_OCC
 lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ counters, uint32_t n_arg,
                  int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* ticket, uint32_t* states)
 {
@@ -152,13 +158,16 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
     // ---- per-digit: scan over the waves, look-back over the tiles, scans over the digits ----
     uint32_t run = 0, gh = 0;
     if (tid < 256) {
-        uint32_t cw[LG_SORT_WAVES];
 #pragma unroll
-        for (int w = 0; w < LG_SORT_WAVES; w++) cw[w] = wcnt[w][tid];       // all reads in flight, then the running sum
+        for (int w0 = 0; w0 < LG_SORT_WAVES; w0 += 4) {                     // four reads in flight, then their running sum
+            uint32_t cw[4];
 #pragma unroll
-        for (int w = 0; w < LG_SORT_WAVES; w++) {
-            wcnt[w][tid] = (unsigned short)run;                            // exclusive over the waves of this tile
-            run += cw[w];
+            for (int w = 0; w < 4; w++) cw[w] = wcnt[w0 + w][tid];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                wcnt[w0 + w][tid] = (unsigned short)run;                   // exclusive over the waves of this tile
+                run += cw[w];
+            }
         }
         gh = hist[tid];
         // publish the tile's aggregate before looking back: nobody ever waits for more than this store

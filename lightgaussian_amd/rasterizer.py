@@ -217,6 +217,8 @@ def _native_forward(lib, call, rs, count):
     key = (dev.index, N, W, H)
     mode = _OPTIONS["sync_free"]
     cap = _CAPACITY.get(key) if (mode and N > 0 and not rs.prefiltered) else None
+    if call.view.flags & _lib.FLAG_PAIR_SORT:
+        cap = None                                 # the pair key format (cross-check switch / fields beyond 64 bits) has no bounded form
     if cap is not None and cap > 0:          # (-1: a depth beyond max_depth was seen for this shape -> exact path for good)
         binning = torch.empty(lib.lg_binning_bytes(cap, W, H), **u8)
         if mode == "validated":
@@ -226,7 +228,10 @@ def _native_forward(lib, call, rs, count):
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
                                         float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), None, C.byref(host), stream)
-            _lib.check(rc)
+            if rc == _lib.LG_ERR_INVALID_ARGUMENT and b"64 key bits" in lib.lg_last_error():
+                host[0] = 2                        # tile | depth | id do not fit one key for this shape: exact path, for good
+            else:
+                _lib.check(rc)
             if host[0] == 0:
                 _note_count(key, int(host[3]))
                 return color, radii, gcount, score, geom, binning, img, cap
