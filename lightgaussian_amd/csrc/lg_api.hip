@@ -246,7 +246,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         {
             ProfScope ps(prof, "duplicate", stream);
-            const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), 256));
+            const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), LG_DUP_GRID));
             if (kp.packed)
                 lg_duplicate<true><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
                                                               geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);

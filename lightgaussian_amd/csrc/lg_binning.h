@@ -125,6 +125,9 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 // and atomics on one address serialise (~12 ns each): 1024 workgroups of 256 threads cost ~1000 atomics per bin, about as long
 // as the rest of the kernel; 256 workgroups of 1024 threads a quarter of that for the same number of waves.
 #define LG_DUP_THREADS 1024
+#ifndef LG_DUP_GRID
+#define LG_DUP_GRID 256        // workgroups (one per CU)
+#endif
 #define LG_DUP_WAVES (LG_DUP_THREADS / 64)
 template <bool PACKED>
 __global__ void __launch_bounds__(LG_DUP_THREADS)

@@ -19,7 +19,7 @@ cd $R
 S=$(find gpurun_out/prof_$MODE -name '*kernel_stats.csv' | head -1)
 C() { find gpurun_out/pmc_${MODE}_$1 -name '*counter_collection.csv' | head -1; }
 python tools/profile_summary.py --mode $MODE --stats $S --fetch $(C 1) --write $(C 2) --sq $(C 3) $(C 4) $(C 5) \
-  --command "rocprofv3 [--kernel-trace --stats | --pmc <set>] -- python bench.py --mode $MODE --no-cpu-baseline --no-roofline --no-literal $@ (tools/gpu_profile.sh)" \
+  --command "rocprofv3 [--kernel-trace --stats | --pmc <set>] -- python bench.py --mode $MODE --no-cpu-baseline --no-roofline --no-literal $* (tools/gpu_profile.sh)" \
   > gpurun_out/r02_profile_$MODE.json
 cp $S gpurun_out/r02_${MODE}_kernel_stats.csv
 head -c 1200 gpurun_out/r02_profile_$MODE.json; echo
