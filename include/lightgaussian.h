@@ -254,7 +254,7 @@ int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const fl
                      const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
                      uint32_t flags, void* stream);
 
-/* Per-tile lists longer than `entries` (default 2048; a multiple of 64) are processed by the backward as independent segments
+/* Per-tile lists longer than `entries` (default 1024; a multiple of 64) are processed by the backward as independent segments
  * of that length, from checkpoints the forward leaves (DESIGN: long-tile robustness).  Process-wide; returns the previous
  * value; must not change between a forward and its backward.  Small values exist for the tests. */
 int lg_set_segment_length(int32_t entries);

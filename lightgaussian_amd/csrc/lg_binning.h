@@ -126,7 +126,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 // as the rest of the kernel; 256 workgroups of 1024 threads a quarter of that for the same number of waves.
 #define LG_DUP_THREADS 1024
 #ifndef LG_DUP_GRID
-#define LG_DUP_GRID 256        // workgroups (one per CU)
+#define LG_DUP_GRID 512        // workgroups (two per CU; 256: 0.050 ms, 512: 0.044 ms at C3)
 #endif
 #define LG_DUP_WAVES (LG_DUP_THREADS / 64)
 template <bool PACKED>

@@ -137,8 +137,10 @@ static ImgView carve_img(void* base, int W, int H)
 // runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry tile becomes ten independent work items
 // instead of one 4 ms serial chain.  Tiles with at most one segment (all of the uniform benchmark scene) never touch the
 // checkpoints.  Process-wide so that the buffer sizes stay functions of (R, W, H); must not change between a forward and
-// its backward.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
-static std::atomic<int> g_segment{2048};
+// its backward.  1024 by measurement: in a dense pile every entry touches all four 8x8 blocks of the tile, and a 2048-entry
+// segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of the uniform benchmark
+// scene stay below 1024.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
+static std::atomic<int> g_segment{1024};
 extern "C" int lg_set_segment_length(int32_t entries)
 {
     const int prev = g_segment.load();

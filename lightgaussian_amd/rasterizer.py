@@ -63,7 +63,7 @@ def set_option(name, value):
               and depths are laid out for max_depth (the camera's zfar; scene/cameras.py:64 uses 100).  A view that does not fit
               is abandoned on the device; pending_overflow() (one sync for a whole batch of views) reports it and raises the
               capacity, and the caller re-renders -- parallel.backward_over_views and the sharded prune pass do."""
-    if name == "segment_length":   # entries per backward segment of a long tile list (library-wide, default 2048; tests use 64)
+    if name == "segment_length":   # entries per backward segment of a long tile list (library-wide, default 1024; tests use 64)
         return _lib.load().lg_set_segment_length(int(value))
     if name not in _OPTIONS:
         raise KeyError(name)

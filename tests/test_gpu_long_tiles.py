@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    rasterizer.set_option("segment_length", 2048)
+    rasterizer.set_option("segment_length", 1024)
 
 
 def _np(kw):
@@ -86,7 +86,7 @@ def test_heavy_tailed_scene_has_long_lists_and_runs_with_the_default_segment():
     from lightgaussian_amd.gaussian_renderer import render
     dev = torch.device("cuda:0")
     g = syn.make_gaussians(400_000, seed=9)
-    syn.make_heavy_tailed(g)
+    syn.make_heavy_tailed(g, frac=0.08)
     pc = g.to(dev).requires_grad_(True)
     cam = syn.orbit_camera(0, 10, 960, 540).to(dev)
     pkg = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))
@@ -95,5 +95,5 @@ def test_heavy_tailed_scene_has_long_lists_and_runs_with_the_default_segment():
     ranges = saved[-2][: T * 8].view(torch.int32).view(T, 2).cpu().numpy()
     n = ranges[:, 1] - ranges[:, 0]
     pkg["render"].sum().backward()
-    assert n.max() > 2 * 2048, n.max()                        # several segments on the densest tiles
+    assert n.max() > 2 * 1024, n.max()                        # several segments on the densest tiles
     assert torch.isfinite(pc._xyz.grad).all() and float(pc._xyz.grad.abs().sum()) > 0

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round-2 measurement run: full suite, smoke, the bench modes / configs quoted in DESIGN.md, profile passes, VQ / compaction
+mkdir -p gpurun_out; export TMPDIR=/tmp
+run() { timeout -s KILL 600 python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+import sys, json
+d=json.loads(sys.stdin.read().strip()); c=d['config']; print('$*', '->', d['value'], 'views/s', d['ms_per_step'], 'ms', 'V', c['visible_gaussians'], 'R', c['tile_instances'], d.get('kernels_ms'), 'steady', (d.get('steady_state') or {}).get('views_per_s'), 'batch3', (d.get('camera_batch_3') or {}), (d.get('significance_pass') or {}), (d.get('literal_getter_pattern') or {}))" | cut -c1-1800; }
+timeout -s KILL 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15 > gpurun_out/r2_final_pytest.log; grep -E "passed|failed" gpurun_out/r2_final_pytest.log | tail -1; grep -E "^FAILED|^E  " gpurun_out/r2_final_pytest.log | head
+timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+( time timeout -s KILL 900 python bench.py ) > gpurun_out/r2_final_bench_default.log 2>&1; tail -5 gpurun_out/r2_final_bench_default.log | cut -c1-6000
+run --n-gaussians 1000000 --mode fwd --steps 100 --no-literal
+run --n-gaussians 3000000 --mode fwd --steps 100 --no-literal
+run --n-gaussians 3000000 --mode count --steps 100
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --no-fuse
+run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 100 --sync-free off --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwdbwd --steps 50 --sh-degree 2 --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwd --steps 50 --sh-degree 3 --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode distill --steps 30 --sh-degree 3
+run --n-gaussians 3000000 --mode fwdbwd --steps 30 --scale 0.012 --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scene heavy --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scale 0.0045 --no-literal
+timeout -s KILL 300 python tools/vq_bench.py 2>&1 | tail -4
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
+bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
+bash tools/gpu_profile.sh count 2>&1 | tail -3 | cut -c1-200
