@@ -16,6 +16,12 @@ import gpu_common  # noqa: E402
 from common import syn  # noqa: E402
 from oracle import oracle  # noqa: E402
 
+if os.environ.get("LG_FUZZ_SEG"):      # e.g. 64: every list longer than 64 entries goes through the segmented backward
+    from lightgaussian_amd import rasterizer as _r
+    _r.set_option("segment_length", int(os.environ["LG_FUZZ_SEG"]))
+if os.environ.get("LG_FUZZ_SYNC"):     # off | validated | nowait
+    from lightgaussian_amd import rasterizer as _r
+    _r.set_option("sync_free", {"off": False, "validated": "validated"}[os.environ["LG_FUZZ_SYNC"]])
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 only = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 bad = 0
