@@ -107,8 +107,10 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 float q[4] = { q4.x, q4.y, q4.z, q4.w };
                 if (RAW) {
                     sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-                    const float inv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); // F.normalize
-                    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+                    // F.normalize = x / max(|x|, eps): a DIVISION per component, as torch evaluates it (a multiplication by the
+                    // reciprocal differs in the last bit, and one such bit can move ceil(3 sigma) -- the radius -- by one)
+                    const float qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+                    q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;
                 }
                 lg_cov3d(sc, mod, q, cov);
             }
@@ -312,8 +314,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
             if (RAW) {
                 sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
                 qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
-                const float inv = 1.0f / qn;
-                q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+                q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;     // exactly K1's operations (division, see there)
             }
             lg_cov3d(sc, mod, q, S);
         }

@@ -75,7 +75,7 @@ for t in range(trials):
 from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused  # noqa: E402
 dev = torch.device("cuda:0")
 bad2 = 0
-n2 = max(10, trials // 4)
+n2 = int(os.environ.get("LG_FUZZ_N2", max(10, trials // 4)))   # LG_FUZZ_N2: size of the fused-getter phase on its own
 for t in range(n2):
     rs = np.random.RandomState(991 + 104729 * t)
     N = int(rs.choice([1, 63, 64, 65, 500, 4099, 20000]))
