@@ -259,6 +259,10 @@ int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const fl
  * value; must not change between a forward and its backward.  Small values exist for the tests. */
 int lg_set_segment_length(int32_t entries);
 
+/* diagnostics: the fused-getter activations on their own (exp; sigmoid in two forms; normalize in four summation orders), n
+ * values each: out_s [n], out_r [4][n][4], out_o [2][n] -- compared with torch's own results by tools/activation_probe.py */
+int lg_debug_activations(int32_t n, const float* s, const float* r, const float* o, float* out_s, float* out_r, float* out_o, void* stream);
+
 /* diagnostics: K4 on its own -- stable ascending sort of bits [begin_bit, end_bit) of n < 2^30 64-bit keys (keys_in preserved);
  * temp: lg_debug_sort_temp_bytes(n) device bytes */
 size_t lg_debug_sort_temp_bytes(int64_t n);

@@ -28,7 +28,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
-           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked"]
+           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked", "lg_debug_activations"]
 
 
 class lg_view(C.Structure):
@@ -122,6 +122,7 @@ def load():
     lib.lg_debug_sort_temp_bytes.restype = C.c_size_t; lib.lg_debug_sort_temp_bytes.argtypes = [C.c_int64]
     lib.lg_debug_sort_keys.restype = C.c_int
     lib.lg_debug_sort_keys.argtypes = [C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp]
+    lib.lg_debug_activations.restype = C.c_int; lib.lg_debug_activations.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.lg_debug_reduce9.restype = C.c_int; lib.lg_debug_reduce9.argtypes = [vp, vp, vp]
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []

@@ -709,6 +709,36 @@ extern "C" int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* 
     return LG_OK;
 }
 
+// diagnostics: the activations of the fused-getter path (K1 / K9, RAW) on their own, in several candidate operation orders,
+// to be compared bit for bit with torch.exp / F.normalize / torch.sigmoid (tools/activation_probe.py)
+__global__ void lg_debug_activations_kernel(int n, const float* __restrict__ s, const float* __restrict__ r, const float* __restrict__ o,
+                                            float* __restrict__ out_s, float* __restrict__ out_r, float* __restrict__ out_o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_s[i] = expf(s[i]);
+    out_o[i] = lg_sigmoid(o[i]);
+    out_o[n + i] = 1.0f / (1.0f + __expf(-o[i]));
+    const float a = r[4 * i], b = r[4 * i + 1], c = r[4 * i + 2], d = r[4 * i + 3];
+    const float n0 = fmaxf(sqrtf(((a * a + b * b) + c * c) + d * d), 1e-12f);
+    const float n1 = fmaxf(sqrtf((a * a + b * b) + (c * c + d * d)), 1e-12f);
+    const float n2 = fmaxf(sqrtf(fmaf(d, d, fmaf(c, c, fmaf(b, b, a * a)))), 1e-12f);
+    const float n3 = fmaxf(sqrtf((a * a + c * c) + (b * b + d * d)), 1e-12f);
+    const float nn[4] = {n0, n1, n2, n3};
+    for (int v = 0; v < 4; v++) {
+        out_r[(size_t)v * 4 * n + 4 * i] = a / nn[v]; out_r[(size_t)v * 4 * n + 4 * i + 1] = b / nn[v];
+        out_r[(size_t)v * 4 * n + 4 * i + 2] = c / nn[v]; out_r[(size_t)v * 4 * n + 4 * i + 3] = d / nn[v];
+    }
+}
+extern "C" int lg_debug_activations(int32_t n, const float* s, const float* r, const float* o, float* out_s, float* out_r, float* out_o, void* stream_p)
+{
+    if (n <= 0) return LG_OK;
+    lg_debug_activations_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_p>>>(n, s, r, o, out_s, out_r, out_o);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_activations launch", e);
+    return LG_OK;
+}
+
 extern "C" int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream_p)
 {
     lg_debug_reduce9_kernel<<<1, 64, 0, (hipStream_t)stream_p>>>(in_64x9, out_9);

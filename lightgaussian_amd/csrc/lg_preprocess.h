@@ -107,9 +107,12 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                 float q[4] = { q4.x, q4.y, q4.z, q4.w };
                 if (RAW) {
                     sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-                    // F.normalize = x / max(|x|, eps): a DIVISION per component, as torch evaluates it (a multiplication by the
-                    // reciprocal differs in the last bit, and one such bit can move ceil(3 sigma) -- the radius -- by one)
-                    const float qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+                    // F.normalize = x / max(|x|, eps), evaluated EXACTLY as torch does on this GPU: squares summed pairwise,
+                    // (a^2 + b^2) + (c^2 + d^2), and a DIVISION per component (tools/activation_probe.py: 0 of 12 M components differ;
+                    // left-to-right summation differs in 10 % of them, a multiplication by the reciprocal in 26 %).  expf and
+                    // 1 / (1 + expf(-x)) equal torch.exp / torch.sigmoid bit for bit as they stand.  One differing bit can move
+                    // ceil(3 sigma) -- the radius -- by one and with it a border tile: 2e-3 in the image of 3 of 500 fuzz scenes.
+                    const float qn = fmaxf(sqrtf((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3])), 1e-12f);
                     q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;
                 }
                 lg_cov3d(sc, mod, q, cov);
@@ -313,8 +316,8 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
             q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
             if (RAW) {
                 sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-                qn = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
-                q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;     // exactly K1's operations (division, see there)
+                qn = fmaxf(sqrtf((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3])), 1e-12f);
+                q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;     // exactly K1's operations (pairwise sum, division: see there)
             }
             lg_cov3d(sc, mod, q, S);
         }

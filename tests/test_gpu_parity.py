@@ -356,9 +356,12 @@ def test_fused_getters_match_unfused_render(deg):
     # bit-identical to the explicit render_fused call
     assert np.array_equal(ic, ib) and np.array_equal(vc, vb) and all(
         (x is None and y is None) or np.array_equal(x, y) for x, y in zip(gb, gc))
+    # round 2: the in-kernel activations reproduce torch.exp / torch.sigmoid / F.normalize bit for bit on this GPU
+    # (tools/activation_probe.py), so the forward of the fused path IS the literal path's forward: radii, image and the
+    # screen-space gradient (which involves no activation) are bit-identical
     assert np.array_equal(ra, rb)
-    assert gpu_common.rel_err(ib, ia) <= 1e-5
-    assert gpu_common.rel_err(vb, va) <= TOL
+    assert np.array_equal(ia, ib), f"image differs: {gpu_common.rel_err(ib, ia):.3e}"
+    assert gpu_common.rel_err(vb, va) <= 1e-6
     for name, x, y in zip(("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"), ga, gb):
         if x is None or x.size == 0:
             continue
