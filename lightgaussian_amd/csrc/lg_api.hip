@@ -162,8 +162,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (binning_out) *binning_out = bounded->binning;
         if (num_rendered) *num_rendered = cap;
         if (N == 0) {
-            HIP_TRY(hipMemsetAsync(geo.counters, 0, 16, stream));
-            HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream));
+            HIP_TRY(lg_zero_async(geo.counters, 16, stream));
+            if (bounded->status) HIP_TRY(lg_zero_async(bounded->status, 16, stream));
+            HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream));
         }
     }
     if (N > 0) {
@@ -191,7 +192,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             lg_scan_blocks<<<(nblk + LG_PART - 1) / LG_PART, LG_PART, 0, stream>>>(nblk, geo.blk_sum, geo.blk_dmax, geo.blk_off, geo.part_sum,
                                                                                   geo.part_dmax, geo.part_prefix, geo.counters + 8,
                                                                                   bounded ? (uint32_t)cap : 0xFFFFFFFFu,
-                                                                                  bounded ? kp.depth_bits : 32, geo.counters);
+                                                                                  bounded ? kp.depth_bits : 32, geo.counters,
+                                                                                  bounded ? (uint32_t*)bounded->status : nullptr);
         }
         KCHECK("lg_scan_blocks");
     }
@@ -220,9 +222,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         bin = carve_bin(bin_p, R, W, H, kp.packed);
         cap = R;
         if (num_rendered) *num_rendered = R;
-        if (R == 0) HIP_TRY(hipMemsetAsync(bin.ranges, 0, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
+        if (R == 0) HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
     } else {
-        if (bounded->status) HIP_TRY(hipMemcpyAsync(bounded->status, geo.counters, 16, hipMemcpyDeviceToDevice, stream));
+        // (bounded->status is written by lg_scan_blocks itself, or cleared above for N == 0: no copy node)
         if (bounded->host_status) {
             // validated mode: the four status words travel to pinned host memory right behind K2; the host waits for them
             // only AFTER everything else of the view has been enqueued (end of this function), so the device never idles
@@ -241,7 +243,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         uint32_t* hist = nullptr;
         if (kp.packed) {
             // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass
-            HIP_TRY(hipMemsetAsync(bin.sort_temp, 0, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
+            HIP_TRY(lg_zero_async(bin.sort_temp, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
             hist = (uint32_t*)((char*)bin.sort_temp + SL.hist_off);
         }
         {

@@ -24,7 +24,7 @@
 __global__ void __launch_bounds__(LG_PART)
 lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* __restrict__ blk_dmax, uint32_t* __restrict__ blk_off,
                uint32_t* part_sum, uint32_t* part_dmax, uint32_t* __restrict__ part_prefix, uint32_t* done, uint32_t capacity,
-               int depth_bits, uint32_t* __restrict__ counters)
+               int depth_bits, uint32_t* __restrict__ counters, uint32_t* __restrict__ status)
 {
     __shared__ uint32_t wsum[16], wmax[16], wflag[16];
     __shared__ uint32_t s_last;
@@ -105,6 +105,9 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
         counters[1] = f;
         counters[2] = m;
         counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
+        if (status) {                                               // the caller's copy of the four words (lg_forward_bounded)
+            status[0] = abort; status[1] = f; status[2] = m; status[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
+        }
         *done = 0u;                                                 // ready for the next view that reuses this buffer
     }
 }

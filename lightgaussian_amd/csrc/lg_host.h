@@ -36,6 +36,22 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
         if (_e != hipSuccess) return fail(LG_ERR_DEVICE, #expr, _e);      \
     } while (0)
 
+// Clear of device words as a KERNEL node.  The forward / backward use this instead of hipMemsetAsync / device-to-device
+// hipMemcpyAsync: inside a captured HIP graph (ROCm 7.2) memset / memcpy nodes between kernel nodes did not keep the kernels
+// behind them ordered after the kernels before them -- replays with a moved camera blended the previous replay's lists
+// (tools/reuse_probe.py graph).  With kernel nodes only, the captured forward / step replays bit-identically.
+__global__ void __launch_bounds__(256) lg_zero_words(uint32_t* __restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline hipError_t lg_zero_async(void* p, size_t bytes, hipStream_t stream)     // bytes % 4 == 0, p 4-byte aligned
+{
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    lg_zero_words<<<(unsigned)std::min<size_t>((n + 255) / 256, 2048), 256, 0, stream>>>((uint32_t*)p, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // optional per-kernel event timing (LG_FLAG_PROFILE)
 struct ProfEntry { std::string name; double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };

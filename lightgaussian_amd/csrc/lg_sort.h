@@ -264,7 +264,7 @@ static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k
     uint64_t* keys_tmp = (uint64_t*)(base + L.keys_tmp_off);
     hipError_t e;
     if (!hist_ready) {
-        if ((e = hipMemsetAsync(base, 0, lg_sort_clear_bytes(L, passes), stream)) != hipSuccess) return e;
+        if ((e = lg_zero_async(base, lg_sort_clear_bytes(L, passes), stream)) != hipSuccess) return e;
         const unsigned hb = (unsigned)std::min<size_t>(((size_t)n + 2047) / 2048, 1024);
         lg_sort_hist<<<hb, 256, 0, stream>>>(keys_in, n, begin_bit, end_bit, hist);
     }
