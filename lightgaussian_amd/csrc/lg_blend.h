@@ -251,6 +251,32 @@ __device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* 
     if (lane == 63u) dst[8] = w8;
 }
 
+// The same sums through LDS (K7's default).  The 9 partials of every lane go to a 9 x 64 matrix `red` (row stride 68 floats:
+// conflict-free for the dwordx4 reads below); lane 4 r + q then adds columns 16 q .. 16 q + 15 of row r (four ds_read_b128,
+// 15 adds) and two quad-DPP adds join the four quarters: 17 VALU instructions per entry instead of the 36 (+ hazard nops) of
+// the register-only fold above -- the fold was a quarter of K7's instruction stream.  The LDS operations of one wave execute
+// in order, so the reads see every lane's writes without a barrier; lanes >= 36 redo row 8 (clamped row: no exec masking).
+#define LG_RED_STRIDE 68
+#define LG_RED_FLOATS (9 * LG_RED_STRIDE)
+__device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float* red, float* dst, uint32_t lane)
+{
+#pragma unroll
+    for (int v = 0; v < 9; v++) red[v * LG_RED_STRIDE + (int)lane] = p[v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t r = min(lane >> 2, 8u), q = lane & 3u;
+    const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
+    const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+    float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+              (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+    s = dpp_add<0xB1, 0xf>(s);                      // quad_perm [1,0,3,2]
+    s = dpp_add<0x4E, 0xf>(s);                      // quad_perm [2,3,0,1]: every lane of the quad holds the row total
+    if (q == 0u && lane < 36u) dst[lane >> 2] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // (the next entry overwrites `red`)
+}
+
 // Gradient rows hold MOMENTS, not finished gradients.  With t = G * dL/dalpha per (pixel, Gaussian) pair, dx = x_g - px:
 //   p[0] = sum t dx   p[1] = sum t dy   p[2] = sum t dx^2   p[3] = sum t dx dy   p[4] = sum t dy^2   p[5] = sum t
 //   p[6..8] = sum alpha T dL/dC_c
@@ -354,8 +380,12 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
              const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
              const float* __restrict__ dL_dpix, const float4* __restrict__ ckpt, float* __restrict__ part)
 {
-    __shared__ float4 q0[LG_Q], q1[LG_Q], q2[LG_Q];
+    __shared__ float4 q0[LG_Q], q1[LG_Q];
+    __shared__ float q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
+#ifndef LG_K7_DPP_REDUCE
+    __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
+#endif
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
     const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
     const int tile = (int)item.x;
@@ -435,24 +465,27 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             trect = tinfo[id];
         }
         if (nb > 0) {
-            float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            // sub-block overlap masks of the whole batch as four 64-bit SCALAR masks (bit j = entry j overlaps sub-block s): the
+            // walk below tests bits and jumps from set bit to set bit -- no per-entry LDS read + readfirstlane round trip
+            bool hit[4] = {false, false, false, false};
             if (lane < nb) {
-                r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
-                uint32_t m = 0;
+                const float4 r0 = rec[LG_REC_F4 * (size_t)id], r1 = rec[LG_REC_F4 * (size_t)id + 1], r2 = rec[LG_REC_F4 * (size_t)id + 2];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
-                    const bool hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
-                    m |= (hit ? 1u : 0u) << s;
+                    hit[s] = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
                 }
-                q0[lane] = r0; q1[lane] = r1; q2[lane] = make_float4(r2.x, r2.y, r2.z, __uint_as_float(m));
+                q0[lane] = r0; q1[lane] = r1; q2[lane] = r2.x;
             }
+            const uint64_t M0 = __ballot(hit[0]), M1 = __ballot(hit[1]), M2 = __ballot(hit[2]), M3 = __ballot(hit[3]);
             __builtin_amdgcn_wave_barrier();
-            for (int j = (int)nb - 1; j >= 0; j--) {
-                const float4 c = q2[j];
-                const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-                if (m == 0) continue;
+            for (uint64_t any = (M0 | M1) | (M2 | M3); any != 0;) {
+                const int j = 63 - __builtin_clzll(any);               // back to front
+                any &= ~(1ull << j);
+                const uint32_t m = (uint32_t)((M0 >> j) & 1ull) | ((uint32_t)((M1 >> j) & 1ull) << 1) | ((uint32_t)((M2 >> j) & 1ull) << 2) |
+                                   ((uint32_t)((M3 >> j) & 1ull) << 3);
                 const float4 a = q0[j], b = q1[j];
+                const float4 c = make_float4(q2[j], 0.0f, 0.0f, 0.0f);
                 const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
                 float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                 bool contrib = false;
@@ -472,7 +505,11 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                     }
                 }
                 if (__ballot(contrib) == 0) continue;
+#ifdef LG_K7_DPP_REDUCE
                 wave_reduce9_to_lds(p, stage + j * 9, lane);
+#else
+                wave_reduce9_via_lds(p, red, stage + j * 9, lane);
+#endif
                 hitmask |= 1ull << j;
             }
             __builtin_amdgcn_wave_barrier();
@@ -492,13 +529,18 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     }
 }
 
-// diagnostics: wave_reduce9_to_lds on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
+// diagnostics: K7's wave reduction (wave_reduce9_via_lds, or _to_lds with -DLG_K7_DPP_REDUCE) on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
 __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
 {
     __shared__ float dst[9];
     float p[9];
     for (int c = 0; c < 9; c++) p[c] = in[threadIdx.x * 9 + c];
+#ifdef LG_K7_DPP_REDUCE
     wave_reduce9_to_lds(p, dst, threadIdx.x);
+#else
+    __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
+    wave_reduce9_via_lds(p, red, dst, threadIdx.x);
+#endif
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
     if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x];

@@ -1,15 +1,17 @@
 #!/bin/bash
-# A/B on ONE box (box-to-box variance is ~5 %): usage  gpu_ab.sh "<bench args>" libA.so libB.so ...   (two rounds, interleaved)
+# A/B of library variants on one box: tools/gpu_ab.sh <mode> <lib-a> <lib-b> ...   ("-" = the in-tree library)
+mode=$1; shift
 mkdir -p gpurun_out
-ARGS="$1"; shift
-for round in 1 2; do
-  for lib in "$@"; do
-    LIGHTGAUSSIAN_HIP_LIB=$PWD/$lib timeout 300 python bench.py $ARGS --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import sys, json
-l=sys.stdin.read().strip()
-try:
-    d=json.loads(l); print('$lib', d['value'], 'ms/step', d['ms_per_step'], d.get('kernels_ms'))
-except Exception as e: print('RAW', l[-1500:])
-" | tee -a gpurun_out/ab.log
-  done
+for rep in 1 2; do
+for lib in "$@"; do
+  if [ "$lib" = "-" ]; then unset LIGHTGAUSSIAN_HIP_LIB; else export LIGHTGAUSSIAN_HIP_LIB=$PWD/$lib; fi
+  timeout -s KILL 300 python bench.py --mode $mode --no-cpu-baseline --no-literal 2>/dev/null | tail -1 > gpurun_out/ab_tmp.json
+  python - "$lib" <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/ab_tmp.json"))
+k = d.get("kernels_ms", {})
+print(sys.argv[1], "value", d["value"], "ms", d["ms_per_step"], "steady", d.get("steady_state", {}).get("views_per_s"),
+      "bwd", k.get("blend_bwd"), "fwd", k.get("blend_fwd"), "batch3", d.get("camera_batch_3", {}).get("views_per_s_per_gpu"), flush=True)
+PY
+done
 done
