@@ -44,6 +44,43 @@ __device__ __forceinline__ float guard_alpha(float alpha, float opacity, float p
     return alpha;
 }
 
+// Does the 8 x 8 pixel block [x0, x0 + 7] x [y0, y0 + 7] hold a pixel the splat can reach (alpha >= 1/255)?
+// First the axis-aligned box of the alpha >= 1/255 ellipse (hx, hy from lg_project; inf = culling off), then the ellipse
+// itself: power(dx, dy) = ha dx^2 + nb dx dy + hc dy^2 is concave, so its maximum over the block is 0 when the centre is
+// inside and otherwise lies on one of the (at most two) block edges that face the centre -- two clamped 1-D maximisations.
+// A block is dropped only when that maximum is below -(ln(255 opacity) + margin): the margin (1e-3 in the exponent, far
+// above the rounding of this estimate and of the per-pixel evaluation, far below anything visible -- it only keeps blocks)
+// makes the test conservative, so every include / exclude decision per pixel is unchanged.  On the benchmark scene the box
+// passes 1.81 blocks per (tile, splat), the ellipse 1.47 (diagonal, elongated splats): a fifth of the pair evaluations.
+struct LgReach { float tau, r2ha, r2hc; bool cull; };
+__device__ __forceinline__ LgReach lg_reach(const float4& r0, const float4& r1, const float4& r2)
+{
+    LgReach e;
+    e.cull = r2.y < 1.0e30f;
+    e.tau = __logf(255.0f * r1.y) + 1.0e-3f;
+    e.r2ha = __builtin_amdgcn_rcpf(2.0f * r0.z);
+    e.r2hc = __builtin_amdgcn_rcpf(2.0f * r1.x);
+    return e;
+}
+__device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1, const float4& r2, const LgReach& e, float x0, float y0)
+{
+    const float x1 = x0 + 7.0f, y1 = y0 + 7.0f;
+    const bool box = (r0.x + r2.y >= x0) && (r0.x - r2.y <= x1) && (r0.y + r2.z >= y0) && (r0.y - r2.z <= y1);
+#ifdef LG_BOX_ONLY
+    return box;
+#else
+    const float ha = r0.z, nb = r0.w, hc = r1.x;
+    const float dxe = fminf(fmaxf(r0.x, x0), x1) - r0.x, dye = fminf(fmaxf(r0.y, y0), y1) - r0.y;   // nearest point of the block
+    // on the vertical line through the nearest point: dy* = -nb dxe / (2 hc), clamped to the block
+    const float dy1 = fminf(fmaxf(r0.y - nb * dxe * e.r2hc, y0), y1) - r0.y;
+    const float p1 = (ha * dxe + nb * dy1) * dxe + hc * dy1 * dy1;
+    const float dx2 = fminf(fmaxf(r0.x - nb * dye * e.r2ha, x0), x1) - r0.x;
+    const float p2 = (ha * dx2 + nb * dye) * dx2 + hc * dye * dye;
+    const bool reach = fmaxf(p1, p2) >= -e.tau;
+    return box && (reach || !e.cull);
+#endif
+}
+
 // Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
 // every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
 template <bool EXACT, bool COLOR = true>
@@ -129,7 +166,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 const uint32_t id = (uint32_t)entries[idx] & gid_mask;
                 r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
                 // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
-                hit = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx1) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by1);
+                hit = lg_block_hit(r0, r1, r2, lg_reach(r0, r1, r2), bx0, by0);
             }
             uint64_t mask = __ballot(hit);
             if (mask == 0) continue;
@@ -470,11 +507,9 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             bool hit[4] = {false, false, false, false};
             if (lane < nb) {
                 const float4 r0 = rec[LG_REC_F4 * (size_t)id], r1 = rec[LG_REC_F4 * (size_t)id + 1], r2 = rec[LG_REC_F4 * (size_t)id + 2];
+                const LgReach reach = lg_reach(r0, r1, r2);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const float bx0 = tbx + (float)((s & 1) * 8), by0 = tby + (float)((s >> 1) * 8);
-                    hit[s] = (r0.x + r2.y >= bx0) && (r0.x - r2.y <= bx0 + 7.0f) && (r0.y + r2.z >= by0) && (r0.y - r2.z <= by0 + 7.0f);
-                }
+                for (int s = 0; s < 4; s++) hit[s] = lg_block_hit(r0, r1, r2, reach, tbx + (float)((s & 1) * 8), tby + (float)((s >> 1) * 8));
                 q0[lane] = r0; q1[lane] = r1; q2[lane] = r2.x;
             }
             const uint64_t M0 = __ballot(hit[0]), M1 = __ballot(hit[1]), M2 = __ballot(hit[2]), M3 = __ballot(hit[3]);
