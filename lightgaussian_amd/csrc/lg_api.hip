@@ -283,16 +283,19 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     // (count / score accumulators of the count variant were cleared by lg_preprocess)
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
-        dim3 grid(ntiles_pad), block(256);
+        // + 1: the last workgroup builds the backward's work list from the tile ranges (colour forwards only: the
+        // significance-only pass has no backward)
+        const bool nocolor_pass = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);
+        dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
@@ -365,14 +368,8 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
     const int S = g_segment.load();
     const uint32_t max_items = (uint32_t)(ntiles + R / S + 1);
-    if (R > 0) {
-        // work list of the backward blend: one item per (tile, segment of S entries), longest first.  Computed here, not in the
-        // forward, so that forward-only renders and the significance pass do not pay for it; it lands in arrays reserved for
-        // it inside the binning buffer (the one write the backward makes to saved state; idempotent).
-        ProfScope ps(prof, "work_order", stream);
-        lg_work_order<<<1, 1024, 0, stream>>>(ntiles, S, bin.ranges, bin.work, bin.meta);
-    }
-    KCHECK("lg_work_order");
+    // (the work list of the backward blend -- one item per (tile, segment of S entries), longest first -- was left in the binning
+    // buffer by the forward: one extra workgroup of lg_blend_fwd)
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
         if (fast)

@@ -311,14 +311,15 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 // wave per item and only ~1.6 items per wave slot, so which items share a slot decides the makespan: handing out the long
 // ones first lets the short ones fill the gaps (longest-processing-time-first; counting sort by length, 256 buckets of 16
 // entries, order inside a bucket arbitrary -- items are independent).  Empty tiles produce no item.  meta[0] = item count.
-__global__ void __launch_bounds__(1024)
-lg_work_order(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work, uint32_t* __restrict__ meta)
+// Runs as ONE EXTRA WORKGROUP of the forward blend (lg_blend_fwd, block index ntiles_pad): the ranges are final by then, and
+// the 10 us a lone workgroup needs for 8160 tiles hide behind the blend instead of standing in front of the backward.
+__device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work,
+                                                   uint32_t* __restrict__ meta, uint32_t* hist /* LDS [256] */,
+                                                   uint32_t* base /* LDS [256] */, uint32_t tid, uint32_t nthreads)
 {
-    __shared__ uint32_t hist[256], base[256];
-    const uint32_t tid = threadIdx.x;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int t = (int)tid; t < T; t += 1024) {
+    for (int t = (int)tid; t < T; t += (int)nthreads) {
         const uint2 r = ranges[t];
         for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S)
             atomicAdd(&hist[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u); // bucket 0 = longest
@@ -330,7 +331,7 @@ lg_work_order(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict_
         meta[0] = acc;
     }
     __syncthreads();
-    for (int t = (int)tid; t < T; t += 1024) {
+    for (int t = (int)tid; t < T; t += (int)nthreads) {
         const uint2 r = ranges[t];
         uint32_t seg = 0;
         for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S, seg++)

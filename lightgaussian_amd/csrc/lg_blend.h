@@ -34,11 +34,11 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad)
 // relative, so on the rare lanes whose alpha lies within 5e-6 (relative) of the threshold the canonical value is
 // used instead (wave-uniform branch, taken for ~1e-5 of the evaluations).  Every include/exclude decision of the
 // fast path then equals the canonical path's, forward and backward alike.
-__device__ __forceinline__ float guard_alpha(float alpha, float opacity, float power_le0)
+__device__ __forceinline__ float guard_alpha(float alpha, float opacity, float power_le0 /* clamped to <= 0 here */)
 {
     const bool near = fabsf(alpha - LG_ALPHA_MIN) < 2.0e-8f;
     if (__ballot(near) != 0) {
-        const float ac = fminf(LG_ALPHA_MAX, opacity * lg_exp(power_le0));
+        const float ac = fminf(LG_ALPHA_MAX, opacity * lg_exp(fminf(power_le0, 0.0f)));
         alpha = near ? ac : alpha;
     }
     return alpha;
@@ -90,10 +90,11 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
 {
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
-    const float pe = fminf(power, 0.0f);
-    const float ex = EXACT ? lg_exp(pe) : __expf(pe);
+    // hardware-exp variant: no clamp of the exponent -- lanes with power > 0 are rejected by `ok` below whatever exp returned
+    // (inf -> alpha 0.99, NaN compares false), and the guard's rare branch clamps for itself
+    const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : __expf(power);
     float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
-    if (!EXACT) alpha = guard_alpha(alpha, b.y, pe);
+    if (!EXACT) alpha = guard_alpha(alpha, b.y, power);
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
@@ -117,9 +118,16 @@ __global__ void __launch_bounds__(256)
 lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt)
+             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
+             uint2* __restrict__ work, uint32_t* __restrict__ meta)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    if (blockIdx.x == (uint32_t)ntiles_pad) {
+        // the one workgroup past the tiles: work list of the backward blend (lg_binning.h), overlapped with the blending
+        uint32_t* scratch = reinterpret_cast<uint32_t*>(&q0[0][0]);
+        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256);
+        return;
+    }
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
     // already give 4 rounds of wave slots; the XCD-interleaved static map stays)
     const int tile = xcd_tile(blockIdx.x, ntiles_pad);
@@ -377,10 +385,9 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
 #pragma clang fp contract(fast)
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
-    const float pe = fminf(power, 0.0f);
-    const float G = __expf(pe);
+    const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
     const float op = b.y;
-    const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, pe); // same decisions as the forward
+    const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (a + 0 * d = a)
     // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
