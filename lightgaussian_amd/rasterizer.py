@@ -155,6 +155,7 @@ class _Call:
 _CAP_LOCK = threading.Lock()
 _CAPACITY = {}      # (device index, N, W, H) -> binning capacity in instances
 _PENDING = []       # (status tensor [4] int32, key) of bounded forwards not yet checked
+_STATUS_OVERRIDE = None   # a [4] int32 tensor (device or pinned host) the next sync-free forwards write their status words to
 
 
 def pending_status():
@@ -242,7 +243,8 @@ def _native_forward(lib, call, rs, count):
                     _CAPACITY[key] = int(int(host[3]) * _OPTIONS["capacity_margin"]) + 4096
             del binning
         else:
-            status = torch.empty(4, dtype=torch.int32, device=dev)
+            # (graph.GraphedStep hands in pinned host words that it polls: the kernels write them directly)
+            status = _STATUS_OVERRIDE if _STATUS_OVERRIDE is not None else torch.empty(4, dtype=torch.int32, device=dev)
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
                                         float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), _ptr(status), None, stream)
