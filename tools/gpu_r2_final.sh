@@ -26,3 +26,5 @@ timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -
 timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
 bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
 bash tools/gpu_profile.sh count 2>&1 | tail -3 | cut -c1-200
+LG_FUZZ_SEG=64 timeout -s KILL 400 python tools/gpu_fuzz.py 150 2>&1 | tail -1
+LG_FUZZ_SYNC=off timeout -s KILL 400 python tools/gpu_fuzz.py 150 2>&1 | tail -1
