@@ -259,6 +259,14 @@ int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const fl
  * value; must not change between a forward and its backward.  Small values exist for the tests. */
 int lg_set_segment_length(int32_t entries);
 
+/* Long tiles of the hardware-exp colour forward (lg_forward / lg_forward_bounded without LG_FLAG exact arithmetic, no
+ * count): 0 = serial walk inside the blend kernel; 2 = the segments of every long tile are walked in parallel
+ * (lg_blend_fwd_seg) and joined by a scan, with an exact re-walk of the one segment in which a pixel terminates (lg_blend_fwd_scan / _rewalk); 1 (default) =
+ * parallel once a view of this process has reported a tile list longer than one segment.  Images agree with the serial walk
+ * to float rounding (regrouped transmittance products), n_contrib exactly; the canonical / count path is always serial.
+ * Returns the previous mode.  No counterpart in the reference (its renderCUDA walks every list serially). */
+int lg_set_long_tile_mode(int32_t mode);
+
 /* diagnostics: the fused-getter activations on their own (exp; sigmoid in two forms; normalize in four summation orders), n
  * values each: out_s [n], out_r [4][n][4], out_o [2][n] -- compared with torch's own results by tools/activation_probe.py */
 int lg_debug_activations(int32_t n, const float* s, const float* r, const float* o, float* out_s, float* out_r, float* out_o, void* stream);

@@ -28,7 +28,8 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
-           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked", "lg_debug_activations"]
+           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked", "lg_debug_activations",
+           "lg_set_long_tile_mode"]
 
 
 class lg_view(C.Structure):
@@ -128,6 +129,7 @@ def load():
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []
     lib.lg_build_id.restype = C.c_char_p; lib.lg_build_id.argtypes = []
     lib.lg_set_segment_length.restype = C.c_int; lib.lg_set_segment_length.argtypes = [C.c_int32]
+    lib.lg_set_long_tile_mode.restype = C.c_int; lib.lg_set_long_tile_mode.argtypes = [C.c_int32]
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
     lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []
     lib.lg_last_stats.restype = C.c_int; lib.lg_last_stats.argtypes = [P(lg_stats)]

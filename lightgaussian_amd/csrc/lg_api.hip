@@ -281,6 +281,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const uint32_t gid_mask = kp.gid_mask;
     const int S = g_segment.load();     // list entries per segment of a long tile (checkpoints for the backward)
     // (count / score accumulators of the count variant were cleared by lg_preprocess)
+    // long tiles of the hardware-exp colour forward go to the parallel kernels below when this process has seen one before
+    // (pinned hint word, read ONCE per call) or on request; the canonical / count variants always walk them serially (bit-pinned)
+    uint32_t* hint = long_hint_word();
+    const int lmode = g_long_mode.load();
+    const bool par_long = !count && fast && cap > 0 && N > 0 &&
+                          (lmode == 2 || (lmode == 1 && hint && *(volatile uint32_t*)hint > (uint32_t)S));
+    const int skip_long = par_long ? 1 : 0;
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         // + 1: the last workgroup builds the backward's work list from the tile ranges (colour forwards only: the
@@ -289,19 +296,31 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
 #undef LAUNCH_FWD
     }
     KCHECK("lg_blend_fwd");
+    if (par_long) {
+        // the work list {tile, segment} was left by the forward's last workgroup; items of one-segment tiles return at once
+        ProfScope ps(prof, "blend_fwd_long", stream);
+        const uint32_t max_items = (uint32_t)(ntiles + cap / S + 1);
+        lg_blend_fwd_seg<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt,
+                                                       bin.ckpt_last);
+        lg_blend_fwd_scan<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
+                                                        bin.ckpt, bin.ckpt_last);
+        lg_blend_fwd_rewalk<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
+                                                          out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
+        KCHECK("lg_blend_fwd_long");
+    }
     if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
         ProfScope ps(prof, "score", stream);
         lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);

@@ -119,13 +119,13 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
-             uint2* __restrict__ work, uint32_t* __restrict__ meta)
+             uint2* __restrict__ work, uint32_t* __restrict__ meta, uint32_t* long_hint, int skip_long)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     if (blockIdx.x == (uint32_t)ntiles_pad) {
         // the one workgroup past the tiles: work list of the backward blend (lg_binning.h), overlapped with the blending
         uint32_t* scratch = reinterpret_cast<uint32_t*>(&q0[0][0]);
-        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256);
+        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, long_hint);
         return;
     }
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
@@ -150,6 +150,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
     // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
     const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
+    if (longt && skip_long) return;      // its segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below)
     // the walk exists twice: tiles of one segment (every tile of the uniform benchmark scene) run the LONG = false copy,
     // which carries neither the segment accumulators nor the boundary test
     auto walk = [&](auto long_tag) {
@@ -228,6 +229,228 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     };
     if (longt) walk(std::true_type{}); else walk(std::false_type{});
     if (COLOR && inside) {   // !COLOR: forward-only significance pass, nothing per pixel is kept
+        const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = fmaf(T, bg[0], C0);
+        out_color[HW + pid] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long tiles of the hardware-exp colour forward, segments in parallel.  The walk of a 24 000-entry list is a serial
+// chain of ~0.65 ms for the one workgroup that owns the tile.  Everything but the early termination is independent of what came
+// before: with T_local starting at 1, a segment yields per pixel P = prod (1 - alpha) and C = sum alpha T_local c over its
+// contributing entries, and the sequential result is T = prod P_s, colour = sum_s (prod_{s' < s} P_s') C_s.
+//   pass 1  lg_blend_fwd_seg : one workgroup per (long tile, segment) from the backward's work list walks its S entries with
+//           no termination test and leaves {P, C} and the last contributing list position per pixel (in the checkpoint slots);
+//   pass 2  lg_blend_fwd_scan: one workgroup per long tile, a thread per pixel: prefix products over the segments.  Pixels that
+//           never come near the termination threshold are finished (image, final T, n_contrib, the checkpoint records {T at
+//           the end of the segment, colour accumulated inside it} the backward starts from); a pixel whose transmittance would
+//           fall under the threshold INSIDE segment s* (T P_s* < 1e-4, with a margin) is parked at s*;
+//   pass 3  lg_blend_fwd_rewalk: one workgroup per (long tile, segment) again: the pixels parked at this segment walk it
+//           sequentially from their true T with the published pair step (fwd_pair) -- exact stop position, exact contributor
+//           index -- and are finished there.  Parallel over the segments like pass 1: no tile waits for a serial chain.
+// Same include / exclude decisions as the serial walk (alpha tests do not depend on T; termination is resolved by the exact
+// re-walk); transmittances are regrouped products, so images agree to float rounding, not bit for bit -- the canonical
+// (count / EXACT) path keeps the serial walk.  The kernels are launched only when an earlier view of this process reported a
+// list longer than one segment (pinned hint word, lg_work_order_body) or on request (lg_set_long_tile_mode).
+__device__ __forceinline__ void fwd_free(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
+                                         float& C0, float& C1, float& C2, uint32_t& last, uint32_t rel)
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    float alpha = fminf(LG_ALPHA_MAX, b.y * __expf(power));
+    alpha = guard_alpha(alpha, b.y, power);
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    const float w = ok ? alpha * T : 0.0f;
+    C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
+    T = ok ? T * (1.0f - alpha) : T;
+    last = ok ? rel : last;
+}
+
+// One batch-by-batch walk of list entries [lo, hi) of a tile by one wave (its 8x8 block): gather, block test, ballot compaction
+// into the wave's LDS queue, then `step(a, b, c, rel)` per hit in list order; `stop()` (wave-uniform) ends the walk early.
+template <typename Step, typename Stop>
+__device__ __forceinline__ void lg_walk_block(uint32_t list0, uint32_t lo, uint32_t hi, const uint64_t* __restrict__ entries, uint32_t gid_mask,
+                                              const float4* __restrict__ rec, float bx0, float by0, float4* q0, float4* q1, float4* q2,
+                                              uint32_t lane, Step step, Stop stop)
+{
+    for (uint32_t base = lo; base < hi; base += LG_Q) {
+        if (stop()) break;
+        const uint32_t idx = base + lane;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (idx < hi) {
+            const uint32_t id = (uint32_t)entries[list0 + idx] & gid_mask;
+            r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
+            hit = lg_block_hit(r0, r1, r2, lg_reach(r0, r1, r2), bx0, by0);
+        }
+        uint64_t mask = __ballot(hit);
+        if (mask == 0) continue;
+        if (hit) {
+            const uint32_t pos = prefix_popc(mask);
+            q0[pos] = r0; q1[pos] = r1; q2[pos] = r2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t j = 0;
+        while (mask) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            step(q0[j], q1[j], q2[j], base + src + 1u);       // rel = 1-based position in the tile's list
+            j++;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+                 const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,
+                 uint32_t* __restrict__ ckpt_last)
+{
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    if (blockIdx.x >= meta[0]) return;
+    const uint2 item = work[blockIdx.x];
+    const int tile = (int)item.x;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    if (n <= (uint32_t)S) return;                                  // a one-segment tile: lg_blend_fwd rendered it
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint32_t lo = item.y * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
+    lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
+                  [&](const float4& a, const float4& b, const float4& c, uint32_t rel) { fwd_free(a, b, c, inside, pxf, pyf, T, C0, C1, C2, last, rel); },
+                  [&]() { return false; });
+    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+    const size_t slot = ((size_t)2 * (range.x / (uint32_t)S) + item.y) * 256 + pix;
+    ckpt[slot] = make_float4(T, C0, C1, C2);
+    ckpt_last[slot] = last;
+}
+
+// pass 2: per long tile, per pixel: prefix products over the segments.  A pixel whose transmittance never comes near the
+// termination threshold is finished here; one that would stop inside segment s* is parked -- {T before s*, colour so far} in
+// the checkpoint slot of s*, s* itself in the last-contributor word of slot 0 -- for lg_blend_fwd_rewalk.
+#define LG_NO_SEG 0xFFFFFFFFu
+__global__ void __launch_bounds__(256)
+lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                  float4* __restrict__ ckpt, uint32_t* __restrict__ ckpt_last)
+{
+    if (blockIdx.x >= meta[0]) return;
+    const uint2 item = work[blockIdx.x];
+    if (item.y != 0u) return;                                       // one scan per tile: the work item of its first segment
+    const int tile = (int)item.x;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    if (n <= (uint32_t)S) return;
+    const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int pxi = tx * LG_TILE + (wave & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (wave >> 1) * 8 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+    float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0, sstar = LG_NO_SEG;
+    if (inside) {
+        for (uint32_t s = 0; s < nseg; s++) {
+            const float4 r = ck[(size_t)s * 256];
+            const uint32_t ll = cl[(size_t)s * 256];
+            const float Tend = T * r.x;
+            // would this pixel stop inside the segment?  (T P_s < 1e-4 up to the rounding of the regrouped product: the margin
+            // only sends a few more pixels through the exact re-walk)
+            if (!(Tend >= LG_T_MIN * 1.001f)) { sstar = s; break; }
+            const float in0 = T * r.y, in1 = T * r.z, in2 = T * r.w;
+            C0 += in0; C1 += in1; C2 += in2;
+            T = Tend;
+            last = ll ? ll : last;
+            ck[(size_t)s * 256] = make_float4(T, in0, in1, in2);   // what the backward starts segment s from
+        }
+        if (sstar == LG_NO_SEG) {
+            const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+            final_T[pid] = T;
+            n_contrib[pid] = last;
+            out_color[pid] = fmaf(T, bg[0], C0);
+            out_color[HW + pid] = fmaf(T, bg[1], C1);
+            out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+        } else {
+            ck[(size_t)sstar * 256] = make_float4(T, C0, C1, C2);
+            if (sstar > 0u) cl[(size_t)sstar * 256] = last;       // (s* = 0: nothing contributed before it)
+        }
+    }
+    cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
+}
+
+// pass 3: one workgroup per (long tile, segment) again; a wave has work only if one of its pixels was parked at this segment.
+// Those pixels walk the segment SEQUENTIALLY from their true T with the published pair step -- exact stop position, exact
+// contributor index -- and are finished here.  (A parked pixel that turns out not to stop inside its segment -- the margin of
+// the scan -- simply keeps walking the following segments the same way: rare, and exact.)
+__global__ void __launch_bounds__(256)
+lg_blend_fwd_rewalk(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+                    const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
+                    float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ ckpt,
+                    const uint32_t* __restrict__ ckpt_last)
+{
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    if (blockIdx.x >= meta[0]) return;
+    const uint2 item = work[blockIdx.x];
+    const int tile = (int)item.x;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    if (n <= (uint32_t)S) return;
+    const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+    float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    const uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    const bool mine = inside && cl[0] == item.y;                    // parked at this segment
+    if (__ballot(mine) == 0) return;
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
+    if (mine) {
+        const float4 st = ck[(size_t)item.y * 256];
+        T = st.x; C0 = st.y; C1 = st.z; C2 = st.w;
+        last = item.y > 0u ? cl[(size_t)item.y * 256] : 0u;
+    }
+    bool dn = !mine;
+    uint32_t cur = item.y, mynext = item.y;                         // mynext: first segment this pixel did not enter
+    for (; cur < nseg && __ballot(!dn) != 0; cur++) {              // wave-uniform
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        uint32_t ls = 0;
+        const bool entered = !dn;
+        const uint32_t lo = cur * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
+        lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
+                      [&](const float4& a, const float4& b, const float4& c, uint32_t rel) {
+                          float alpha = 0.0f, w = 0.0f;
+                          (void)fwd_pair<false, true>(a, b, c, !dn, pxf, pyf, T, s0, s1, s2, dn, ls, rel, alpha, w);
+                      },
+                      [&]() { return __ballot(!dn) == 0; });
+        if (entered) {
+            C0 += s0; C1 += s1; C2 += s2;
+            last = ls ? ls : last;
+            ck[(size_t)cur * 256] = make_float4(T, s0, s1, s2);
+            mynext = cur + 1u;
+        }
+    }
+    if (mine) {
+        for (uint32_t j = mynext; j < nseg; j++) ck[(size_t)j * 256] = make_float4(T, 0.0f, 0.0f, 0.0f);   // segments never entered
         const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
         final_T[pid] = T;
         n_contrib[pid] = last;

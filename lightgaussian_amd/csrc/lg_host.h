@@ -157,6 +157,27 @@ static ImgView carve_img(void* base, int W, int H)
 // segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of the uniform benchmark
 // scene stay below 1024.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
 static std::atomic<int> g_segment{1024};
+// Long tiles of the hardware-exp colour forward: 0 = serial walk inside lg_blend_fwd, 2 = always the parallel kernels
+// (lg_blend_fwd_seg / _scan / _rewalk), 1 (default) = parallel once a view of this process has reported a list longer than one segment
+// through the pinned hint word (the uniform benchmark scene never does and never pays the two extra launches).
+static std::atomic<int> g_long_mode{1};
+static uint32_t* g_long_hint = nullptr;      // pinned host word, written by the device (lg_work_order_body), read by the host
+static std::once_flag g_long_hint_once;
+static uint32_t* long_hint_word()
+{
+    std::call_once(g_long_hint_once, [] {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) { memset(p, 0, 64); g_long_hint = (uint32_t*)p; }
+    });
+    return g_long_hint;
+}
+extern "C" int lg_set_long_tile_mode(int32_t mode)
+{
+    const int prev = g_long_mode.load();
+    if (mode >= 0 && mode <= 2) g_long_mode.store(mode);
+    if (mode == 1 && long_hint_word()) *(volatile uint32_t*)long_hint_word() = 0u;   // "auto" starts from a clean hint
+    return prev;
+}
 extern "C" int lg_set_segment_length(int32_t entries)
 {
     const int prev = g_segment.load();
@@ -169,6 +190,8 @@ struct BinView {
     uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
     uint32_t* meta;                 // [16] 0 = number of work items (lg_work_order)
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
+    uint32_t* ckpt_last;            // [2 (R / S + 1)][256] last contributing list position per (segment, pixel): pass 1 -> join of
+                                    //     the parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk)
     uint64_t* entries;              // [R] sorted list entries; the low bits_for(N) bits are the Gaussian id.  Packed format:
                                     //     these ARE the sorted keys (tile | depth | id).  Pairs format: written by lg_tile_ranges
     uint64_t* keys_in;              // [R] radix-sort input
@@ -193,6 +216,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
     v.work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
     v.meta = (uint32_t*)take(64);
     v.ckpt = (float4*)take(2 * (n / S + 1) * 256 * 16);
+    v.ckpt_last = (uint32_t*)take(2 * (n / S + 1) * 256 * 4);
     v.entries = (uint64_t*)take(n * 8);
     v.keys_in = (uint64_t*)take(n * 8);
     size_t tb = 0;

@@ -65,6 +65,8 @@ def set_option(name, value):
               capacity, and the caller re-renders -- parallel.backward_over_views and the sharded prune pass do."""
     if name == "segment_length":   # entries per backward segment of a long tile list (library-wide, default 1024; tests use 64)
         return _lib.load().lg_set_segment_length(int(value))
+    if name == "long_tiles":       # "serial" | "auto" (default) | "parallel": lg_set_long_tile_mode (DESIGN 18)
+        return ("serial", "auto", "parallel")[_lib.load().lg_set_long_tile_mode({"serial": 0, "auto": 1, "parallel": 2}[value])]
     if name not in _OPTIONS:
         raise KeyError(name)
     _OPTIONS[name] = value

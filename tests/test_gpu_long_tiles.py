@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 def _restore():
     yield
     rasterizer.set_option("segment_length", 1024)
+    rasterizer.set_option("long_tiles", "serial")
 
 
 def _np(kw):
@@ -97,3 +98,79 @@ def test_heavy_tailed_scene_has_long_lists_and_runs_with_the_default_segment():
     pkg["render"].sum().backward()
     assert n.max() > 2 * 1024, n.max()                        # several segments on the densest tiles
     assert torch.isfinite(pc._xyz.grad).all() and float(pc._xyz.grad.abs().sum()) > 0
+
+
+# ---- parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk): segments walked independently, joined by a scan with an
+# ---- exact re-walk where a pixel terminates
+PAR_SCENES = SCENES + [dict(N=6000, W=160, H=96, scale=0.08, opm=-0.5, seed=6),      # semi-opaque, deep: pixels saturate inside later segments
+                       dict(N=4000, W=130, H=70, scale=0.1, opm=2.5, seed=7)]        # opaque: saturation inside the first segment
+
+
+@pytest.mark.parametrize("sc", PAR_SCENES, ids=lambda s: f"N{s['N']}_{s['W']}x{s['H']}_op{s['opm']}")
+@pytest.mark.parametrize("S", [64, 128])
+def test_parallel_long_tile_forward_matches_the_serial_walk(sc, S):
+    """Same include / exclude decisions, transmittances as regrouped products: the image agrees with the serial walk to float
+    rounding, the gradients (which start from the forward's checkpoints, final T and n_contrib) to 2e-5 of each other and
+    within the usual bound of the float64 oracle (5e-5 of each other on the opaque scenes)."""
+    kw = _scene(**sc)
+    gimg = np.random.RandomState(8).randn(3, sc["H"], sc["W"]).astype(np.float32)
+    rasterizer.set_option("segment_length", S)
+    rasterizer.set_option("long_tiles", "serial")
+    a = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    assert rasterizer.set_option("long_tiles", "parallel") == "serial"
+    b = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    assert np.array_equal(a["radii"], b["radii"])
+    assert np.abs(a["color"] - b["color"]).max() <= 3e-6, np.abs(a["color"] - b["color"]).max()
+    ref64 = oracle.forward(dtype=np.float64, **_np(kw)); g64 = oracle.backward(ref64, gimg)
+    ref32 = oracle.forward(**_np(kw)); g32 = oracle.backward(ref32, gimg)
+    assert np.abs(b["color"] - ref32.color).max() <= 1e-5
+    for name in a["grads"]:
+        r = g64[name]
+        floor = gpu_common.rel_err(g32[name], r)
+        assert gpu_common.rel_err(b["grads"][name].reshape(r.shape), r) <= max(1e-4, 3.0 * floor), name
+        # (opaque scenes amplify the last-bit differences of T through the backward's T / (1 - alpha) replay)
+        assert gpu_common.rel_err(b["grads"][name], a["grads"][name]) <= max(5e-5, 4.0 * floor), name
+
+
+def test_parallel_long_tile_forward_leaves_n_contrib_and_final_T_of_the_serial_walk():
+    """The per-pixel outputs the backward starts from: n_contrib (index of the last contributor: exact -- terminations are
+    resolved by the sequential re-walk) and final T (to float rounding), read from the saved image state."""
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    W, H = 192, 128
+    g = syn.make_gaussians(20000, seed=5, log_scale_mean=math.log(0.03), opacity_mean=-0.5, extent=(2, 1.2, 2))
+    syn.make_heavy_tailed(g, frac=0.3, radius=0.3, log_scale_mean=math.log(0.06), opacity_mean=-2.0)
+    pc = g.to(dev)
+    cam = syn.orbit_camera(1, 7, W, H, radius=5.0).to(dev)
+    rasterizer.set_option("segment_length", 64)
+    outs = {}
+    for mode in ("serial", "parallel"):
+        rasterizer.set_option("long_tiles", mode)
+        pkg = render(cam, pc.requires_grad_(True), syn.PipelineParams(), torch.zeros(3, device=dev))
+        img = pkg["render"].grad_fn.saved_tensors[-1]
+        P = W * H
+        off = ((P * 4 + 255) // 256) * 256
+        outs[mode] = (pkg["render"].detach().clone(), img[: P * 4].view(torch.float32).clone(), img[off: off + P * 4].view(torch.int32).clone())
+    assert int(outs["serial"][2].max()) > 4 * 64                 # lists of many segments were walked
+    assert (outs["serial"][1] < 1e-3).float().mean() > 0.01        # and some pixels did saturate (the re-walk ran)
+    assert torch.equal(outs["serial"][2], outs["parallel"][2])
+    assert float((outs["serial"][1] - outs["parallel"][1]).abs().max()) <= 1e-6
+    assert float((outs["serial"][0] - outs["parallel"][0]).abs().max()) <= 3e-6
+
+
+def test_long_tile_mode_auto_switches_after_the_first_long_view():
+    """ "auto" (the library default): the first view with a long list is walked serially and raises the pinned hint word; later
+    views take the parallel kernels.  Uniform scenes (no list beyond one segment) never raise it."""
+    sc = SCENES[3]
+    kw = _scene(**sc)
+    rasterizer.set_option("segment_length", 64)
+    rasterizer.set_option("long_tiles", "serial")
+    serial = gpu_common.hip_forward_backward(kw)["color"]
+    rasterizer.set_option("long_tiles", "parallel")
+    parallel = gpu_common.hip_forward_backward(kw)["color"]
+    assert not np.array_equal(serial, parallel)                    # (regrouped products: the two paths are distinguishable)
+    rasterizer.set_option("long_tiles", "auto")                    # starts from a clean hint
+    first = gpu_common.hip_forward_backward(kw)["color"]
+    torch.cuda.synchronize()
+    second = gpu_common.hip_forward_backward(kw)["color"]
+    assert np.array_equal(first, serial) and np.array_equal(second, parallel)
