@@ -262,7 +262,7 @@ int lg_set_segment_length(int32_t entries);
 /* Long tiles of the hardware-exp colour forward (lg_forward / lg_forward_bounded without LG_FLAG exact arithmetic, no
  * count): 0 = serial walk inside the blend kernel; 2 = the segments of every long tile are walked in parallel
  * (lg_blend_fwd_seg) and joined by a scan, with an exact re-walk of the one segment in which a pixel terminates (lg_blend_fwd_scan / _rewalk); 1 (default) =
- * parallel once a view of this process has reported a tile list longer than one segment.  Images agree with the serial walk
+ * the same for lists longer than two segments and four times the view's mean list, once a view of this process has reported one.  Images agree with the serial walk
  * to float rounding (regrouped transmittance products), n_contrib exactly; the canonical / count path is always serial.
  * Returns the previous mode.  No counterpart in the reference (its renderCUDA walks every list serially). */
 int lg_set_long_tile_mode(int32_t mode);

@@ -285,9 +285,19 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     // (pinned hint word, read ONCE per call) or on request; the canonical / count variants always walk them serially (bit-pinned)
     uint32_t* hint = long_hint_word();
     const int lmode = g_long_mode.load();
-    const bool par_long = !count && fast && cap > 0 && N > 0 &&
-                          (lmode == 2 || (lmode == 1 && hint && *(volatile uint32_t*)hint > (uint32_t)S));
-    const int skip_long = par_long ? 1 : 0;
+    // "auto" sends a list through the parallel kernels when it is longer than two segments AND four times the mean list of the
+    // view: such a list is the forward's critical path (its serial walk outlasts everything else), shorter ones are not.
+    // Measured (fwd+bwd views/s, heavy-tailed scene / 6 M Gaussians at 1600x1060): every multi-segment list 466 / 310;
+    // > 2 S 459 / 338; > 3 S 439 / 356; > 4 S 411 / 352; > 8 S 380 / 347; serial only 416 / 353.  With the mean-relative rule the
+    // dense scene (mean list 1200) launches nothing and the heavy-tailed one (mean 545, lists to 24 000) uses > 2180.
+    const uint64_t r_est = bounded ? (uint64_t)cap * 4 / 5 : (uint64_t)cap;    // (a bounded view knows its capacity = 1.25 R + 4096)
+    const uint32_t hint_min = std::max(2u * (uint32_t)S, (uint32_t)std::min<uint64_t>(4 * r_est / (uint64_t)std::max(ntiles, 1), 1u << 30));
+    uint32_t par_min = 0;                             // 0 = every list is walked serially by lg_blend_fwd
+    if (!count && fast && cap > 0 && N > 0) {
+        if (lmode == 2) par_min = (uint32_t)S;
+        else if (lmode == 1 && hint && *(volatile uint32_t*)hint > hint_min) par_min = hint_min;   // (the hint: longest list an earlier view reported)
+    }
+    const bool par_long = par_min != 0u;
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         // + 1: the last workgroup builds the backward's work list from the tile ranges (colour forwards only: the
@@ -296,13 +306,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, skip_long);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
@@ -313,11 +323,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         // the work list {tile, segment} was left by the forward's last workgroup; items of one-segment tiles return at once
         ProfScope ps(prof, "blend_fwd_long", stream);
         const uint32_t max_items = (uint32_t)(ntiles + cap / S + 1);
-        lg_blend_fwd_seg<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt,
+        lg_blend_fwd_seg<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt,
                                                        bin.ckpt_last);
-        lg_blend_fwd_scan<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
+        lg_blend_fwd_scan<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
                                                         bin.ckpt, bin.ckpt_last);
-        lg_blend_fwd_rewalk<<<max_items, 256, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
+        lg_blend_fwd_rewalk<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
                                                           out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
         KCHECK("lg_blend_fwd_long");
     }

@@ -318,12 +318,12 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 // entries, order inside a bucket arbitrary -- items are independent).  Empty tiles produce no item.  meta[0] = item count.
 // Runs as ONE EXTRA WORKGROUP of the forward blend (lg_blend_fwd, block index ntiles_pad): the ranges are final by then, and
 // the 10 us a lone workgroup needs for 8160 tiles hide behind the blend instead of standing in front of the backward.
-// It also tells the HOST that this view has tiles longer than one segment: `long_hint` (may be NULL) is a word of pinned host
+// It also tells the HOST that this view has tiles longer than hint_min entries: `long_hint` (may be NULL) is a word of pinned host
 // memory that the next forwards read to decide whether the parallel long-tile kernels are worth launching (lg_blend_fwd_seg).
 __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work,
                                                    uint32_t* __restrict__ meta, uint32_t* hist /* LDS [256] */,
                                                    uint32_t* base /* LDS [257] */, uint32_t tid, uint32_t nthreads,
-                                                   uint32_t* long_hint)
+                                                   uint32_t* long_hint, uint32_t hint_min)
 {
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) base[256] = 0;
@@ -335,13 +335,13 @@ __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __
         for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S)
             atomicAdd(&hist[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u); // bucket 0 = longest
     }
-    if (longest > (uint32_t)S) atomicMax(&base[256], longest);
+    if (longest > hint_min) atomicMax(&base[256], longest);
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; }
         meta[0] = acc;
-        meta[1] = base[256];                                    // longest list of the view when it exceeds one segment, else 0
+        meta[1] = base[256];                                    // longest list of the view when it exceeds hint_min, else 0
         if (long_hint && base[256] != 0u) {
             __hip_atomic_store(long_hint, base[256], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -119,13 +119,13 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
-             uint2* __restrict__ work, uint32_t* __restrict__ meta, uint32_t* long_hint, int skip_long)
+             uint2* __restrict__ work, uint32_t* __restrict__ meta, uint32_t* long_hint, uint32_t hint_min, uint32_t par_min)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     if (blockIdx.x == (uint32_t)ntiles_pad) {
         // the one workgroup past the tiles: work list of the backward blend (lg_binning.h), overlapped with the blending
         uint32_t* scratch = reinterpret_cast<uint32_t*>(&q0[0][0]);
-        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, long_hint);
+        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, long_hint, hint_min);
         return;
     }
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
@@ -150,7 +150,8 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
     // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
     const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
-    if (longt && skip_long) return;      // its segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below)
+    // lists longer than par_min (when set): their segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below)
+    if (longt && par_min != 0u && (range.y - range.x) > par_min) return;
     // the walk exists twice: tiles of one segment (every tile of the uniform benchmark scene) run the LONG = false copy,
     // which carries neither the segment accumulators nor the boundary test
     auto walk = [&](auto long_tag) {
@@ -254,8 +255,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 //           index -- and are finished there.  Parallel over the segments like pass 1: no tile waits for a serial chain.
 // Same include / exclude decisions as the serial walk (alpha tests do not depend on T; termination is resolved by the exact
 // re-walk); transmittances are regrouped products, so images agree to float rounding, not bit for bit -- the canonical
-// (count / EXACT) path keeps the serial walk.  The kernels are launched only when an earlier view of this process reported a
-// list longer than one segment (pinned hint word, lg_work_order_body) or on request (lg_set_long_tile_mode).
+// (count / EXACT) path keeps the serial walk.  Which lists: the free-running pass evaluates every entry for every pixel (the
+// serial walk stops when its 64 pixels are saturated) and costs three more launches, so it pays only for lists whose serial
+// walk would BE the forward's critical path.  "auto" (lg_api.hip) takes lists longer than two segments and four times the
+// view's mean list, and only once an earlier view of the process has reported one (pinned hint word, lg_work_order_body): the
+// uniform benchmark scene never launches these kernels; lg_set_long_tile_mode(2) sends every multi-segment list (tests).
 __device__ __forceinline__ void fwd_free(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
                                          float& C0, float& C1, float& C2, uint32_t& last, uint32_t rel)
 {
@@ -306,7 +310,7 @@ __device__ __forceinline__ void lg_walk_block(uint32_t list0, uint32_t lo, uint3
 }
 
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_seg(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                  const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,
                  uint32_t* __restrict__ ckpt_last)
 {
@@ -316,7 +320,7 @@ lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ work, co
     const int tile = (int)item.x;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    if (n <= (uint32_t)S) return;                                  // a one-segment tile: lg_blend_fwd rendered it
+    if (n <= par_min) return;                                      // (par_min >= S) a shorter list: lg_blend_fwd rendered it
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -341,7 +345,7 @@ lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ work, co
 // the checkpoint slot of s*, s* itself in the last-contributor word of slot 0 -- for lg_blend_fwd_rewalk.
 #define LG_NO_SEG 0xFFFFFFFFu
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_scan(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                   const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   float4* __restrict__ ckpt, uint32_t* __restrict__ ckpt_last)
 {
@@ -351,7 +355,7 @@ lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ work, c
     const int tile = (int)item.x;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    if (n <= (uint32_t)S) return;
+    if (n <= par_min) return;
     const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
@@ -397,7 +401,7 @@ lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ work, c
 // contributor index -- and are finished here.  (A parked pixel that turns out not to stop inside its segment -- the margin of
 // the scan -- simply keeps walking the following segments the same way: rare, and exact.)
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_rewalk(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_rewalk(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                     const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
                     float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ ckpt,
                     const uint32_t* __restrict__ ckpt_last)
@@ -408,7 +412,7 @@ lg_blend_fwd_rewalk(int W, int H, int gx, int S, const uint2* __restrict__ work,
     const int tile = (int)item.x;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    if (n <= (uint32_t)S) return;
+    if (n <= par_min) return;
     const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;

@@ -157,9 +157,10 @@ static ImgView carve_img(void* base, int W, int H)
 // segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of the uniform benchmark
 // scene stay below 1024.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
 static std::atomic<int> g_segment{1024};
-// Long tiles of the hardware-exp colour forward: 0 = serial walk inside lg_blend_fwd, 2 = always the parallel kernels
-// (lg_blend_fwd_seg / _scan / _rewalk), 1 (default) = parallel once a view of this process has reported a list longer than one segment
-// through the pinned hint word (the uniform benchmark scene never does and never pays the two extra launches).
+// Long tiles of the hardware-exp colour forward: 0 = serial walk inside lg_blend_fwd; 2 = every multi-segment list through the
+// parallel kernels (lg_blend_fwd_seg / _scan / _rewalk); 1 (default) = lists longer than two segments and four times the view's
+// mean list through them, once a view of this process has reported such a list through the pinned hint word (the uniform
+// benchmark scene never does and never pays the three extra launches).
 static std::atomic<int> g_long_mode{1};
 static uint32_t* g_long_hint = nullptr;      // pinned host word, written by the device (lg_work_order_body), read by the host
 static std::once_flag g_long_hint_once;
