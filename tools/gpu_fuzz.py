@@ -19,6 +19,9 @@ from oracle import oracle  # noqa: E402
 if os.environ.get("LG_FUZZ_SEG"):      # e.g. 64: every list longer than 64 entries goes through the segmented backward
     from lightgaussian_amd import rasterizer as _r
     _r.set_option("segment_length", int(os.environ["LG_FUZZ_SEG"]))
+if os.environ.get("LG_FUZZ_LONG"):     # serial | auto | parallel: walk of multi-segment lists in the training forward
+    from lightgaussian_amd import rasterizer as _r
+    _r.set_option("long_tiles", os.environ["LG_FUZZ_LONG"])
 if os.environ.get("LG_FUZZ_SYNC"):     # off | validated | nowait
     from lightgaussian_amd import rasterizer as _r
     _r.set_option("sync_free", {"off": False, "validated": "validated"}[os.environ["LG_FUZZ_SYNC"]])
