@@ -80,3 +80,24 @@ def test_product_never_imports_the_oracle():
         assert "oracle" not in txt.replace("(the reference has no CPU", ""), path
     for path in glob.glob(os.path.join(common.ROOT, "lightgaussian_amd", "csrc", "*")):
         assert "lg_oracle" not in open(path).read(), path
+
+
+def test_process_wide_setters_return_the_previous_value_and_reject_nonsense():
+    """lg_set_segment_length / lg_set_long_tile_mode (no device needed: host state only)."""
+    lib = _lib.load()
+    prev = lib.lg_set_segment_length(128)
+    try:
+        assert lib.lg_set_segment_length(100) == 128          # not a multiple of 64: ignored ...
+        assert lib.lg_set_segment_length(32) == 128           # ... as is anything below 64
+        assert lib.lg_set_segment_length(256) == 128
+        assert lib.lg_binning_bytes(100000, 640, 480) > 0
+    finally:
+        lib.lg_set_segment_length(prev)
+    mode = lib.lg_set_long_tile_mode(0)                       # 0 serial, 1 auto (default), 2 parallel
+    try:
+        assert mode in (0, 1, 2)
+        assert lib.lg_set_long_tile_mode(2) == 0
+        assert lib.lg_set_long_tile_mode(7) == 2 and lib.lg_set_long_tile_mode(-1) == 2   # out of range: unchanged
+        assert lib.lg_set_long_tile_mode(0) == 2
+    finally:
+        lib.lg_set_long_tile_mode(0 if mode == 1 else mode)  # (mode 1 touches pinned host memory: not from a test without a device)
