@@ -543,10 +543,10 @@ def main():
                                        "frac_of_8TBps": round(b8d * value / world / 1e9 / HBM_PEAK_GBS, 4)}
         result["kernels_ms_note"] = "per-kernel hipEvent brackets (separate untimed pass) add ~4 % each: their sum exceeds ms_per_step"
         if args.mode == "fwdbwd" and dom == "blend_bwd":
-            # The live duration of the VALU-bound blend kernels is ~14 % above rocprofv3's (K6 and K7 by the same factor; the
-            # memory-bound K1 / K9 agree to 2-3 %).  Not a warm-up or thermal effect: measured here with the device idling 4 ms
-            # right before the backward of every step, the duration is the same as inside back-to-back steps.  What is left is
-            # the clock the device grants a VALU-saturating kernel outside the profiler.
+            # The hipEvent bracket of the VALU-bound blend kernels reads ~14 % above rocprofv3's duration (K6 and K7 by the same
+            # factor; the memory-bound K1 / K9 agree to 2-3 %).  Not a warm-up or thermal effect: measured here with the device
+            # idling 4 ms right before the backward of every step, the bracket reads the same.  The rocprof durations are the ones
+            # that add up to the measured step; the cause of the difference is not established.
             rasterizer.set_option("profile", True)
             _lib.profile_reset()
             for i in range(nprof):
@@ -568,7 +568,7 @@ def main():
                 result["roofline"]["avg_launch_ms_after_idle"] = round(prof2[dom][0] / prof2[dom][1], 4)
                 result["roofline"]["avg_launch_ms_note"] = ("avg_launch_ms: inside back-to-back steps; avg_launch_ms_after_idle: the device idles 4 ms "
                                                             "before each backward; profiled_avg_launch_ms: rocprofv3 --kernel-trace --stats of the same "
-                                                            "command (VALU-bound kernels run ~14 % shorter under the profiler, memory-bound ones do not)")
+                                                            "command (the brackets of the VALU-bound kernels read ~14 % above it, those of the memory-bound ones 2-3 %; the rocprof durations are the ones that sum to the measured step)")
 
     # ---- the same step with the reference's literal getter pattern (torch exp/sigmoid/normalize/cat per call), untimed leg ----
     if rank == 0 and not args.no_fuse and not args.no_literal and args.mode in ("fwdbwd", "fwd", "distill"):
