@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count", "distill"], default="fwdbwd")
+    ap.add_argument("--no-distill-overlap", action="store_true", help="--mode distill: teacher and student forwards in sequence on one stream")
     ap.add_argument("--n-gaussians", type=int, default=3_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -286,10 +287,8 @@ def main():
         elif args.mode == "distill":
             for p in sparams:
                 p.grad = None
-            with torch.no_grad():
-                target = render(cams[k], pc, pipe, bg)["render"]
-            loss = (render(cams[k], student, pipe, bg)["render"] - target).abs().mean()
-            loss.backward()
+            # teacher forward on a side stream next to the student's forward (parallel.distill_step; --no-distill-overlap: in sequence)
+            parallel.distill_step(pc, student, cams[k], pipe, bg, loss_fn=lambda a, b: (a - b).abs().mean(), overlap=not args.no_distill_overlap)
             if collectives:   # the rank-0-only measurement legs below must not enter a collective
                 parallel.allreduce_gradients(sparams)
         else:

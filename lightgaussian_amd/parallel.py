@@ -150,6 +150,42 @@ def make_student(teacher, sh_degree):
                               teacher._rotation.detach().clone(), teacher._opacity.detach().clone(), sh_degree, sh_degree)
 
 
+_TEACHER_STREAMS = {}
+
+
+def distill_step(teacher, student, camera, pipe, background, loss_fn=None, render_fn=None, overlap=True):
+    """One distillation iteration of distill_train.py:124-146 up to loss.backward(): teacher render (no grad), student render,
+    loss between the two, backward through the student.  Returns (loss, teacher image, student render package).
+
+    overlap=True (default): the two forwards are independent until the loss, so the teacher's is issued on a side stream of
+    the device and runs next to the student's -- each forward spends a third of its time in the latency-bound binning chain
+    (scan / duplicate / 4 sort passes), which the other one's blend fills.  Same kernels, same order per stream: images, loss
+    and gradients are bit-identical to the sequential form (overlap=False)."""
+    from .gaussian_renderer import render
+    from . import loss_utils
+    render_fn = render_fn or render
+    loss_fn = loss_fn or loss_utils.l1_loss_only
+    dev = student._xyz.device
+    cur = torch.cuda.current_stream(dev)
+    if not overlap:
+        with torch.no_grad():
+            target = render_fn(camera, teacher, pipe, background)["render"]
+        pkg = render_fn(camera, student, pipe, background)
+    else:
+        side = _TEACHER_STREAMS.get((dev.index, cur.cuda_stream))
+        if side is None:
+            side = _TEACHER_STREAMS[(dev.index, cur.cuda_stream)] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)                         # the teacher's parameters / the camera may have just been written
+        with torch.cuda.stream(side), torch.no_grad():
+            target = render_fn(camera, teacher, pipe, background)["render"]
+        pkg = render_fn(camera, student, pipe, background)
+        cur.wait_stream(side)
+        target.record_stream(cur)                     # allocated on the side stream, consumed on this one
+    loss = loss_fn(pkg["render"], target)
+    loss.backward()
+    return loss, target, pkg
+
+
 _RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
 

@@ -88,3 +88,32 @@ def test_overlapped_gradient_allreduce_through_rccl():
             assert torch.equal(getattr(pc3, n).grad, ref[n]), n
     finally:
         dist.destroy_process_group()
+
+
+def test_distill_step_with_the_teacher_on_a_side_stream_equals_the_sequential_form():
+    """parallel.distill_step (distill_train.py:124-146): teacher forward on a side stream next to the student's forward.  Same
+    kernels in the same order per stream: loss, teacher image and the student's gradients are bit-identical to the sequential
+    form, over several cameras and with an optimizer-like in-place update of the student between the steps."""
+    g, _cam, pipe, bg, _ = _setup(N=20_011)
+    teacher = _model(g)
+    for n in NAMES:
+        getattr(teacher, n).requires_grad_(False)
+    cams = [syn.orbit_camera(k, 9, 240, 160).to(DEV) for k in range(5)]
+    results = {}
+    for overlap in (False, True):
+        student = parallel.make_student(teacher, 2).requires_grad_(True)
+        out = []
+        for cam in cams:
+            for n in NAMES:
+                getattr(student, n).grad = None
+            loss, target, pkg = parallel.distill_step(teacher, student, cam, pipe, bg, overlap=overlap)
+            out.append((float(loss), target.clone(), pkg["render"].detach().clone(), _grads(student)))
+            with torch.no_grad():                                   # what an optimizer step does to the leaves
+                student._xyz.add_(student._xyz.grad, alpha=-1e-3)
+                student._features_dc.add_(student._features_dc.grad, alpha=-1e-2)
+        results[overlap] = out
+    for a, b in zip(results[False], results[True]):
+        assert a[0] == b[0] and a[0] > 0
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for n in NAMES:
+            assert torch.equal(a[3][n], b[3][n]), n
