@@ -560,6 +560,7 @@ def main():
                 loss.backward()
                 torch.cuda.synchronize()
                 time.sleep(0.004)
+            del loss
             prof2 = _lib.profile_read()
             rasterizer.set_option("profile", False)
             _lib.profile_reset()

@@ -59,14 +59,15 @@ class GraphedStep:
             raise ValueError("loss must be 'l1' or 'l1_dssim'")
         self.pc, self.pipe, self.bg, self.mod = pc, pipe, bg_color, float(scaling_modifier)
         self.loss_kind, self.lam, self.check = loss, float(lambda_dssim), check
-        self._graphs = {}          # camera key -> (graph, static camera, static target, static loss, status tensor, model id, capacity key, grads)
+        self._graphs = {}          # camera key -> (graph, static camera, static target, static loss, status tensor, model id, capacity key, grads, leaf view)
         self.replays = self.captures = self.repairs = 0
 
     # -- the step itself (eager form; also what gets captured) -------------------------------------------------------
-    def _body(self, cam, gt):
+    def _body(self, cam, gt, model=None):
+        model = self.pc if model is None else model
         for n in _PARAMS:
-            getattr(self.pc, n).grad = None
-        image = render(cam, self.pc, self.pipe, self.bg, self.mod)["render"]
+            getattr(model, n).grad = None
+        image = render(cam, model, self.pipe, self.bg, self.mod)["render"]
         if self.loss_kind == "l1":
             loss = loss_utils.l1_loss_only(image, gt)
         else:
@@ -85,20 +86,26 @@ class GraphedStep:
             self._body(static_cam, static_gt)                     # learns the binning capacity of this shape (exact path first)
             _rast.set_option("sync_free", True)
             _rast.pending_status()
+            # The step runs on fresh autograd LEAVES that share the parameters' storage (parallel._LeafView), one set for the
+            # warm-up and one for the capture: an AccumulateGrad node remembers the stream it was created on, and the
+            # parameters' own nodes -- alive for as long as the caller holds any tensor of an earlier eager step -- were
+            # created on the caller's stream; backward inside the capture would then synchronise with that stream (with the
+            # legacy default stream: an invalid capture; this crashed hipStreamEndCapture).  The views' nodes are born on the
+            # stream that uses them.  Gradients are handed to the parameters' .grad after every replay.
+            from .parallel import _LeafView
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):                         # warm-up off the capture stream, as graph capture asks for
-                self._body(static_cam, static_gt)
+                self._body(static_cam, static_gt, _LeafView(self.pc))
             torch.cuda.current_stream(dev).wait_stream(side)
             _rast.pending_status()
-            for n in _PARAMS:
-                getattr(self.pc, n).grad = None                   # .grad tensors are allocated inside the graph's pool
+            view = _LeafView(self.pc)                             # its .grad tensors are allocated inside the graph's pool
             status = torch.full((4,), -1, dtype=torch.int32).pin_memory()   # written by K2 of every replay, polled by the host
             graph = torch.cuda.CUDAGraph()
             _rast._STATUS_OVERRIDE = status
             try:
                 with torch.cuda.graph(graph):
-                    static_loss = self._body(static_cam, static_gt)
+                    static_loss = self._body(static_cam, static_gt, view)
             finally:
                 _rast._STATUS_OVERRIDE = None
             with _rast._CAP_LOCK:
@@ -111,8 +118,10 @@ class GraphedStep:
         finally:
             _rast.set_option("sync_free", saved)
         self.captures += 1
-        grads = [getattr(self.pc, n).grad for n in _PARAMS]       # static: every replay writes these tensors
-        entry = (graph, static_cam, static_gt, static_loss, bounded[0][0], self._model_id(), bounded[0][1], grads)
+        grads = [getattr(view, n).grad for n in _PARAMS]          # static: every replay writes these tensors
+        for n, t in zip(_PARAMS, grads):
+            getattr(self.pc, n).grad = t
+        entry = (graph, static_cam, static_gt, static_loss, bounded[0][0], self._model_id(), bounded[0][1], grads, view)
         self._graphs[static_cam.key()] = entry
         return entry
 
@@ -128,7 +137,7 @@ class GraphedStep:
             if _rast._CAPACITY.get(dkey, 0) < 0:
                 return self._eager(cam, gt)                       # a depth beyond max_depth was seen for this shape: exact path only
             entry = self._capture(cam, gt)
-        graph, static_cam, static_gt, static_loss, status, _n, cap_key, grads = entry
+        graph, static_cam, static_gt, static_loss, status, _n, cap_key, grads, _view = entry
         static_cam.load(cam)
         static_gt.copy_(gt, non_blocking=True)
         words = status.numpy()                                    # the pinned words themselves (no copy)

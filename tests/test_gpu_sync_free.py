@@ -189,6 +189,10 @@ def test_a_whole_training_step_is_graph_capturable():
         loss.backward()
         return float(loss), [getattr(pc, n).grad.clone() for n in names]
 
+    # a tensor of an earlier eager step that the caller still holds keeps the parameters' AccumulateGrad nodes (and the stream
+    # they were created on) alive: the captured step must not depend on them (it runs on leaf views of the parameters)
+    held = loss_utils.l1_loss_only(render(cams[0], pc, pipe, bg)["render"], targets[0])
+    held.backward()
     for kind in ("l1", "l1_dssim"):
         ref = [eager(k, kind) for k in range(len(cams))]
         step = GraphedStep(pc, pipe, bg, loss=kind, lambda_dssim=0.2)
@@ -218,3 +222,4 @@ def test_a_whole_training_step_is_graph_capturable():
         assert float(loss) == ref[4][0] and step.repairs == 1 and step.captures == 2
         for n, r in zip(names, ref[4][1]):
             assert torch.equal(getattr(pc, n).grad, r), (kind, "recapture", n)
+    assert held.grad_fn is not None
