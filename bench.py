@@ -64,7 +64,7 @@ def parse():
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3; HIP lg_loss_forward with LG_FLAG_L1_ONLY), l1_torch (the same "
                          "in torch ops), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
-    ap.add_argument("--count-streams", type=int, default=3, help="--mode count: views in flight per rank (host threads x HIP streams)")
+    ap.add_argument("--count-streams", type=int, default=4, help="--mode count: views in flight per rank (host threads x HIP streams)")
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="fwdbwd/fwd: render this many independent views concurrently (host threads x HIP streams, gradients "
                          "accumulated per thread as in a camera batch > 1); 1 = the reference's one view per step")

@@ -296,7 +296,7 @@ def _ordered_sum(rows, out=None):
 
 
 def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False,
-                       streams=3, block=24, local_only=False, host_threads=False):
+                       streams=4, block=24, local_only=False, host_threads=False):
     """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same Gaussians; returns the same
     (gaussian_list, imp_list) on every rank, bit-identical to the reference loop (mode="ordered") for every world size.
     Without an initialised process group (or at world size 1 unless force_collectives, or with local_only=True inside a
@@ -306,7 +306,8 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
     block:   views per rank per round.  The pass keeps a running sum and absorbs the views round by round in the reference's
              order, so scratch memory is O(block * N) floats per rank whatever the number of views (the reference's loop is
              O(N); the first version of this function held all V score vectors, O(V * N)).
-    Measured at C3 on one MI355X: streams 1 -> 1158, 2 -> 1061, 3 -> 1341, 4 -> 1326 views/s (identical results)."""
+    Measured at C3 on one MI355X (identical results): round 1, a host thread per stream: streams 1 -> 1158, 2 -> 1061, 3 -> 1341,
+    4 -> 1326 views/s; round 2, one host thread: 3 -> 1540, 4 -> 1579, 6 -> 1513 (heavy-tailed scene: 1336 / 1412 / 1299)."""
     from . import rasterizer
     prev = rasterizer._OPTIONS["skip_color_in_count"]
     rasterizer.set_option("skip_color_in_count", True)   # the pass discards the images: do not read 192 B of SH per Gaussian per view
