@@ -19,7 +19,10 @@
  *   - every pointer is a DEVICE pointer into memory owned by the caller, fp32 contiguous unless noted
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
  *   - functions return LG_OK or a negative error code; lg_last_error() gives the message
- *   - the library keeps no state between calls (re-entrant per stream)
+ *   - the library keeps no state between calls that can change a result (re-entrant per stream): everything a view depends
+ *     on travels in lg_view / lg_gaussians and in the caller's buffers.  What it does keep is bookkeeping only: the
+ *     thread-local text of lg_last_error() / lg_last_stats(), a pool of pinned 64-byte read-back slots, and the optional
+ *     LG_FLAG_PROFILE event list
  */
 #ifndef LIGHTGAUSSIAN_H
 #define LIGHTGAUSSIAN_H
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 4
+#define LG_ABI_VERSION 5
 
 enum {
     LG_OK = 0,
@@ -59,6 +62,13 @@ enum {
     LG_FLAG_PAIR_SORT = 64,      /* cross-check switches (never needed in production): force the (tile<<32|depth, id) */
     LG_FLAG_SORT_ALL_BITS = 128, /* pair format; sort every depth bit (no insertion completion in K5); K1 stages SH rows through */
     LG_FLAG_K1_LDS = 256,        /* LDS instead of per-lane dwordx4 reads */
+    LG_FLAG_LONG_SERIAL = 512,   /* long per-tile lists of the hardware-exp colour forward: walk every list serially inside the blend kernel */
+    LG_FLAG_LONG_PARALLEL = 1024, /* ... walk the segments of EVERY multi-segment list in parallel (lg_blend_fwd_seg / _scan / _rewalk).
+                              Neither flag (default): only lists longer than two segments and four times the view's mean list --
+                              decided on the device from this view's own instance count, so the choice never depends on what the
+                              process rendered before.  Images of the parallel walk agree with the serial one to float rounding
+                              (regrouped transmittance products), n_contrib exactly; canonical / count forwards are always serial.
+                              No counterpart in the reference (its renderCUDA walks every list serially). */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc
@@ -79,6 +89,11 @@ typedef struct lg_view {
     const float* campos;     /* [3] */
     int32_t prefiltered;
     uint32_t flags;          /* LG_FLAG_* */
+    int32_t segment_length;  /* per-tile lists longer than this many entries are processed by the backward as independent segments,
+                                from checkpoints the forward leaves (long-tile robustness).  0 = default (1024); otherwise a
+                                multiple of 64 (small values exist for tests).  The SAME lg_view must be handed to lg_forward* and
+                                to the lg_backward of that view, and to lg_binning_bytes: the forward records the value in the
+                                binning buffer and a backward called with another one writes zero gradients (LG_FLAG_DEBUG: error). */
 } lg_view;
 
 /* the 8 tensor kwargs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:106-115); means2D is gradient-only */
@@ -99,7 +114,7 @@ typedef struct lg_gaussians {
  * instance lists for `num_rendered` instances; backward scratch: one 48-byte gradient row per instance. */
 size_t lg_geom_bytes(int32_t N);
 size_t lg_img_bytes(int32_t width, int32_t height);
-size_t lg_binning_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t lg_binning_bytes(int64_t num_rendered, int32_t width, int32_t height, int32_t segment_length /* lg_view.segment_length */);
 size_t lg_backward_scratch_bytes(int32_t N, int64_t num_rendered);
 
 /* Called once per forward, after the instance count is known, to obtain the binning buffer
@@ -133,12 +148,13 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  * Capacity-bounded forward: the same render (plain when out_count/out_score are NULL, else + significance) WITHOUT the
  * blocking device->host read of the instance count that lg_forward -- like the reference extension, whose Python side
  * sizes its binning buffer from num_rendered (SURVEY 8b "one blocking D->H read of R per forward") -- performs.  The
- * caller supplies the binning buffer for up to `max_rendered` instances (lg_binning_bytes(max_rendered, W, H); e.g.
+ * caller supplies the binning buffer for up to `max_rendered` instances (lg_binning_bytes(max_rendered, W, H, S); e.g.
  * 1.25x the previous view's count) and an upper bound `max_depth` of the view-space depth (the camera's zfar), which fixes
  * the key layout on the host.  Nothing is read back and every launch is stream-ordered, so a view's forward + backward can
  * be issued from one host thread onto several streams, or captured into a hipGraph.
  *   status: device uint32[4], written on `stream` = { abort flags, prefiltered violation, largest depth bit pattern,
- *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth.  When status[0] != 0 the
+ *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth (bit 2, set later if ever:
+ *           the radix sort's look-back gave up -- see lg_view_status).  When status[0] != 0 the
  *           view was abandoned on the device (every later kernel returns at once; outputs undefined, gradients of a
  *           following lg_backward are zero) and the caller re-runs it through lg_forward -- the only host decision left.
  *   host_status: NULL, or HOST uint32[4] receiving the same four words before the call returns ("validated" mode).  The
@@ -254,18 +270,11 @@ int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const fl
                      const float* dL_dl1, float scale_l1, const float* dL_dssim, float scale_ssim, float* dL_dimg,
                      uint32_t flags, void* stream);
 
-/* Per-tile lists longer than `entries` (default 1024; a multiple of 64) are processed by the backward as independent segments
- * of that length, from checkpoints the forward leaves (DESIGN: long-tile robustness).  Process-wide; returns the previous
- * value; must not change between a forward and its backward.  Small values exist for the tests. */
-int lg_set_segment_length(int32_t entries);
-
-/* Long tiles of the hardware-exp colour forward (lg_forward / lg_forward_bounded without LG_FLAG exact arithmetic, no
- * count): 0 = serial walk inside the blend kernel; 2 = the segments of every long tile are walked in parallel
- * (lg_blend_fwd_seg) and joined by a scan, with an exact re-walk of the one segment in which a pixel terminates (lg_blend_fwd_scan / _rewalk); 1 (default) =
- * the same for lists longer than two segments and four times the view's mean list, once a view of this process has reported one.  Images agree with the serial walk
- * to float rounding (regrouped transmittance products), n_contrib exactly; the canonical / count path is always serial.
- * Returns the previous mode.  No counterpart in the reference (its renderCUDA walks every list serially). */
-int lg_set_long_tile_mode(int32_t mode);
+/* The four status words of a view as they stand when `stream` reaches this call (one blocking 16-byte read): { abort flags,
+ * prefiltered violation, largest depth bit pattern, instance count }.  abort bit 2: a look-back of the radix sort exhausted its
+ * poll budget (a predecessor tile never published: a device fault, never observed) -- the view was left EMPTY instead of being
+ * blended from a wrong order, and this call (like any forward with LG_FLAG_DEBUG) returns LG_ERR_DEVICE. */
+int lg_view_status(const void* geom, int32_t N, uint32_t* out4 /* host */, void* stream);
 
 /* diagnostics: the fused-getter activations on their own (exp; sigmoid in two forms; normalize in four summation orders), n
  * values each: out_s [n], out_r [4][n][4], out_o [2][n] -- compared with torch's own results by tools/activation_probe.py */
@@ -276,6 +285,10 @@ int lg_debug_activations(int32_t n, const float* s, const float* r, const float*
 size_t lg_debug_sort_temp_bytes(int64_t n);
 int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, int32_t begin_bit, int32_t end_bit, void* temp,
                        void* stream);
+
+/* diagnostics: the failure path of the sort's look-back -- one digit pass whose only tile has a predecessor that never publishes.
+ * Must return LG_ERR_DEVICE (error word set, no hang, no silent wrong order).  temp: lg_debug_sort_temp_bytes(2 * 8192). */
+int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, void* temp, void* stream);
 
 /* diagnostics: the packed wave reduction used by the backward blend, on one wave: in [64][9] -> out [9] */
 int lg_debug_reduce9(const float* in_64x9, float* out_9, void* stream);

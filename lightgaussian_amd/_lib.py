@@ -21,6 +21,7 @@ LG_ERR_PREFILTERED = -4
 WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
 FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_L1_ONLY = 1, 2, 4, 8, 16, 32
 FLAG_PAIR_SORT, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
+FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
@@ -28,15 +29,15 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_loss_forward", "lg_loss_backward", "lg_prune_scratch_bytes", "lg_prune_epilogue", "lg_knn_scratch_bytes",
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
-           "lg_debug_sort_keys", "lg_build_id", "lg_set_segment_length", "lg_backward_chunked", "lg_debug_activations",
-           "lg_set_long_tile_mode"]
+           "lg_debug_sort_keys", "lg_build_id", "lg_backward_chunked", "lg_debug_activations", "lg_view_status",
+           "lg_debug_sort_orphan"]
 
 
 class lg_view(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("bg", C.c_void_p), ("scale_modifier", C.c_float), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("sh_degree", C.c_int32), ("campos", C.c_void_p),
-                ("prefiltered", C.c_int32), ("flags", C.c_uint32)]
+                ("prefiltered", C.c_int32), ("flags", C.c_uint32), ("segment_length", C.c_int32)]
 
 
 class lg_gaussians(C.Structure):
@@ -81,7 +82,7 @@ def load():
     vp, P = C.c_void_p, C.POINTER
     lib.lg_geom_bytes.restype = C.c_size_t; lib.lg_geom_bytes.argtypes = [C.c_int32]
     lib.lg_img_bytes.restype = C.c_size_t; lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
-    lib.lg_binning_bytes.restype = C.c_size_t; lib.lg_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.lg_binning_bytes.restype = C.c_size_t; lib.lg_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
     lib.lg_backward_scratch_bytes.restype = C.c_size_t; lib.lg_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
     lib.lg_forward.restype = C.c_int
     lib.lg_forward.argtypes = [P(lg_view), P(lg_gaussians), vp, vp, ALLOC_FN, vp, vp, vp, P(vp), P(C.c_int64), vp]
@@ -128,8 +129,8 @@ def load():
     lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
     lib.lg_last_error.restype = C.c_char_p; lib.lg_last_error.argtypes = []
     lib.lg_build_id.restype = C.c_char_p; lib.lg_build_id.argtypes = []
-    lib.lg_set_segment_length.restype = C.c_int; lib.lg_set_segment_length.argtypes = [C.c_int32]
-    lib.lg_set_long_tile_mode.restype = C.c_int; lib.lg_set_long_tile_mode.argtypes = [C.c_int32]
+    lib.lg_view_status.restype = C.c_int; lib.lg_view_status.argtypes = [vp, C.c_int32, P(C.c_uint32 * 4), vp]
+    lib.lg_debug_sort_orphan.restype = C.c_int; lib.lg_debug_sort_orphan.argtypes = [C.c_int64, vp, vp, vp, vp]
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
     lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []
     lib.lg_last_stats.restype = C.c_int; lib.lg_last_stats.argtypes = [P(lg_stats)]

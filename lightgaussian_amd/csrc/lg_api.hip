@@ -38,6 +38,10 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
 {
     if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
     if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (v->segment_length != 0 && (v->segment_length < 64 || v->segment_length % 64 != 0))
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_view.segment_length must be 0 (default 1024) or a multiple of 64");
+    if ((v->flags & LG_FLAG_LONG_SERIAL) && (v->flags & LG_FLAG_LONG_PARALLEL))
+        return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_LONG_SERIAL and LG_FLAG_LONG_PARALLEL exclude each other");
     if (g->N == 0) return LG_OK; // nothing to validate against: empty tensors carry no pointers
     if (g->N >= (1 << LG_ID_BITS)) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^29-1 Gaussians (the blend record packs the id in 29 bits)");
     if ((g->shs == nullptr) == (g->colors_precomp == nullptr))
@@ -146,6 +150,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const int nblk = (N + LG_PP - 1) / LG_PP;
     GeomView geo = carve_geom(geom_p, N);
     ImgView img = carve_img(img_p, W, H);
+    const int S = lg_segment_of(v);     // list entries per segment of a long tile (checkpoints for the backward): part of the view
     if (binning_out) *binning_out = nullptr;
     if (num_rendered) *num_rendered = 0;
 
@@ -158,7 +163,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         kp = make_key_plan(ntiles, N, __builtin_bit_cast(uint32_t, bounded->max_depth), v->flags);
         if (!kp.packed) return fail(LG_ERR_INVALID_ARGUMENT, "lg_forward_bounded: tile | depth | id exceed 64 key bits; use lg_forward");
         cap = bounded->capacity;
-        bin = carve_bin(bounded->binning, cap, W, H, true);
+        bin = carve_bin(bounded->binning, cap, W, H, true, S);
         if (binning_out) *binning_out = bounded->binning;
         if (num_rendered) *num_rendered = cap;
         if (N == 0) {
@@ -216,10 +221,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         R = h_counters[3];
         if (R >= (1ll << 30)) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^30-1 tile instances in one view");
         kp = make_key_plan(ntiles, N, h_counters[2], v->flags);
-        void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, kp.packed).total);
+        void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, kp.packed, S).total);
         if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
         if (binning_out) *binning_out = bin_p;
-        bin = carve_bin(bin_p, R, W, H, kp.packed);
+        bin = carve_bin(bin_p, R, W, H, kp.packed, S);
         cap = R;
         if (num_rendered) *num_rendered = R;
         if (R == 0) HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
@@ -279,25 +284,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         KCHECK("lg_tile_ranges");
     }
     const uint32_t gid_mask = kp.gid_mask;
-    const int S = g_segment.load();     // list entries per segment of a long tile (checkpoints for the backward)
     // (count / score accumulators of the count variant were cleared by lg_preprocess)
-    // long tiles of the hardware-exp colour forward go to the parallel kernels below when this process has seen one before
-    // (pinned hint word, read ONCE per call) or on request; the canonical / count variants always walk them serially (bit-pinned)
-    uint32_t* hint = long_hint_word();
-    const int lmode = g_long_mode.load();
-    // "auto" sends a list through the parallel kernels when it is longer than two segments AND four times the mean list of the
-    // view: such a list is the forward's critical path (its serial walk outlasts everything else), shorter ones are not.
-    // Measured (fwd+bwd views/s, heavy-tailed scene / 6 M Gaussians at 1600x1060): every multi-segment list 466 / 310;
-    // > 2 S 459 / 338; > 3 S 439 / 356; > 4 S 411 / 352; > 8 S 380 / 347; serial only 416 / 353.  With the mean-relative rule the
-    // dense scene (mean list 1200) launches nothing and the heavy-tailed one (mean 545, lists to 24 000) uses > 2180.
-    const uint64_t r_est = bounded ? (uint64_t)cap * 4 / 5 : (uint64_t)cap;    // (a bounded view knows its capacity = 1.25 R + 4096)
-    const uint32_t hint_min = std::max(2u * (uint32_t)S, (uint32_t)std::min<uint64_t>(4 * r_est / (uint64_t)std::max(ntiles, 1), 1u << 30));
-    uint32_t par_min = 0;                             // 0 = every list is walked serially by lg_blend_fwd
-    if (!count && fast && cap > 0 && N > 0) {
-        if (lmode == 2) par_min = (uint32_t)S;
-        else if (lmode == 1 && hint && *(volatile uint32_t*)hint > hint_min) par_min = hint_min;   // (the hint: longest list an earlier view reported)
-    }
-    const bool par_long = par_min != 0u;
+    // Long tiles of the hardware-exp colour forward: which lists go through the parallel kernels below is decided ON THE DEVICE
+    // from this view's own instance count (lg_par_min, lg_binning.h) -- no history, no host hint: two renders of the same
+    // inputs run the same kernels on the same lists whatever the process rendered before.  LG_FLAG_LONG_SERIAL / _PARALLEL
+    // override the default rule per call; the canonical / count variants always walk serially (bit-pinned).
+    const int long_mode = (!count && fast && cap > 0 && N > 0) ? ((v->flags & LG_FLAG_LONG_SERIAL) ? 0 : (v->flags & LG_FLAG_LONG_PARALLEL) ? 2 : 1) : 0;
+    const bool par_long = long_mode != 0;
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         // + 1: the last workgroup builds the backward's work list from the tile ranges (colour forwards only: the
@@ -306,13 +299,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, hint, hint_min, par_min);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
@@ -320,21 +313,28 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     }
     KCHECK("lg_blend_fwd");
     if (par_long) {
-        // the work list {tile, segment} was left by the forward's last workgroup; items of one-segment tiles return at once
+        // persistent grids over the par_work list left by the forward's work-list workgroup (meta[4] items; none on scenes
+        // without outlier lists: each launch is then one scalar load per workgroup)
         ProfScope ps(prof, "blend_fwd_long", stream);
-        const uint32_t max_items = (uint32_t)(ntiles + cap / S + 1);
-        lg_blend_fwd_seg<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt,
-                                                       bin.ckpt_last);
-        lg_blend_fwd_scan<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
-                                                        bin.ckpt, bin.ckpt_last);
-        lg_blend_fwd_rewalk<<<max_items, 256, 0, stream>>>(W, H, gx, S, par_min, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
-                                                          out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
+        const uint32_t pgrid = (uint32_t)std::min<int64_t>((int64_t)ntiles + cap / S + 1, LG_PAR_GRID);
+        lg_blend_fwd_seg<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt, bin.ckpt_last);
+        lg_blend_fwd_scan<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
+                                                    bin.ckpt, bin.ckpt_last);
+        lg_blend_fwd_rewalk<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
+                                                      out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
         KCHECK("lg_blend_fwd_long");
     }
     if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
         ProfScope ps(prof, "score", stream);
         lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
         KCHECK("lg_score_kernel");
+    }
+    if (debug && N > 0) {
+        // debug: the abort word as it stands at the END of the view (the radix sort's look-back can only report after K2)
+        uint32_t h_abort = 0;
+        HIP_TRY(hipMemcpyAsync(&h_abort, geo.counters, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h_abort & LG_ABORT_SORT) return fail(LG_ERR_DEVICE, "radix sort look-back gave up (a predecessor tile never published): the view is void");
     }
     if (bounded && bounded->host_status) {
         HIP_TRY(hipEventSynchronize(vslot.ev));            // K2's words are here; the blend kernels are still running
@@ -391,11 +391,11 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     const int ntiles_pad = (ntiles + LG_TILE_GRID_ALIGN - 1) / LG_TILE_GRID_ALIGN * LG_TILE_GRID_ALIGN; // grid of the per-tile kernels
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
-    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true); // only the format-independent prefix is used
+    const int S = lg_segment_of(v);   // must be the forward's (same lg_view); the kernels compare it with meta[2] and refuse otherwise
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true, S); // only the format-independent prefix is used
     const int gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));          // same field width as the forward used
     const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd
-    const int S = g_segment.load();
     const uint32_t max_items = (uint32_t)(ntiles + R / S + 1);
     // (the work list of the backward blend -- one item per (tile, segment of S entries), longest first -- was left in the binning
     // buffer by the forward: one extra workgroup of lg_blend_fwd)
@@ -424,7 +424,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     lg_preprocess_bwd<RAWP><<<nb, LG_PP, 0, stream>>>(                                                                                \
         N, first_blk, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
         g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec,   \
-        geo.counters, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        geo.counters, bin.meta, (uint32_t)S, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
             if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
 #undef LAUNCH_PPB
@@ -432,6 +432,12 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
         }
     }
     KCHECK("lg_preprocess_bwd");
+    if (debug && R > 0) {
+        uint32_t h_seg = 0;
+        HIP_TRY(hipMemcpyAsync(&h_seg, bin.meta + 2, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h_seg != (uint32_t)S) return fail(LG_ERR_INVALID_ARGUMENT, "lg_backward: lg_view.segment_length differs from the forward's (gradients are zero)");
+    }
     return LG_OK;
 }
 
@@ -732,8 +738,53 @@ extern "C" int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* 
     if (n < 0 || n >= (1ll << 30) || begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit) return fail(LG_ERR_INVALID_ARGUMENT, "bad sort arguments");
     if (n == 0) return LG_OK;
     if (!keys_in || !keys_out || !temp) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
-    size_t tb = lg_sort_layout((size_t)n).total;
+    const LgSortLayout L = lg_sort_layout((size_t)n);
+    size_t tb = L.total;
     HIP_TRY(lg_sort_keys(temp, tb, keys_in, keys_out, (uint32_t)n, begin_bit, end_bit, nullptr, false, (hipStream_t)stream_p));
+    uint32_t h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, (char*)temp + L.ticket_off + 15 * 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream_p));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_p));
+    if (h_err & LG_ABORT_SORT) return fail(LG_ERR_DEVICE, "radix sort look-back gave up (a predecessor tile never published)");
+    return LG_OK;
+}
+
+// diagnostics: the failure path of the look-back.  One digit pass is launched with its ticket counter preset to 1, so the tile
+// that runs has a predecessor (tile 0) that does not exist and never publishes; with a small poll budget the look-back must give
+// up, set the error word and return -- LG_ERR_DEVICE here -- instead of hanging the device or passing a wrong order on silently.
+extern "C" int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, void* temp, void* stream_p)
+{
+    if (n <= 0 || n > LG_SORT_TILE) return fail(LG_ERR_INVALID_ARGUMENT, "lg_debug_sort_orphan: 1 <= n <= one sort tile");
+    if (!keys_in || !keys_out || !temp) return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
+    hipStream_t stream = (hipStream_t)stream_p;
+    const LgSortLayout L = lg_sort_layout((size_t)2 * LG_SORT_TILE);
+    char* base = (char*)temp;
+    HIP_TRY(lg_zero_async(base, lg_sort_clear_bytes(L, 1), stream));
+    const uint32_t one = 1u;
+    HIP_TRY(hipMemcpyAsync(base + L.ticket_off, &one, 4, hipMemcpyHostToDevice, stream));
+    uint32_t* tickets = (uint32_t*)(base + L.ticket_off);
+    // n_arg = one tile beyond the orphan so that tile 1 is inside the key range; it sorts keys_in[0..n) as its own keys
+    lg_onesweep_pass<<<1, LG_SORT_BLOCK, 0, stream>>>(keys_in - LG_SORT_TILE, keys_out - LG_SORT_TILE, nullptr, (uint32_t)(LG_SORT_TILE + n), 0, 8,
+                                                       (uint32_t*)(base + L.hist_off), tickets, (uint32_t*)(base + L.state_off), tickets + 15, 64u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_onesweep_pass launch", e);
+    uint32_t h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, tickets + 15, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h_err & LG_ABORT_SORT) return fail(LG_ERR_DEVICE, "radix sort look-back gave up (a predecessor tile never published)");
+    return LG_OK;
+}
+
+// The four status words of a view as they stand when `stream` reaches this call: { abort flags, prefiltered violation,
+// largest depth bit pattern, instance count }.  One blocking 16-byte read.  abort bit 2 (LG_ABORT_SORT) can only be set
+// after the words lg_forward_bounded hands out were written, so a caller that must know reads them here.
+extern "C" int lg_view_status(const void* geom, int32_t N, uint32_t* out4, void* stream_p)
+{
+    if (!geom || !out4 || N < 0) return fail(LG_ERR_INVALID_ARGUMENT, "lg_view_status: missing buffer");
+    GeomView geo = carve_geom(const_cast<void*>(geom), N);
+    hipStream_t stream = (hipStream_t)stream_p;
+    HIP_TRY(hipMemcpyAsync(out4, geo.counters, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (out4[0] & LG_ABORT_SORT) return fail(LG_ERR_DEVICE, "radix sort look-back gave up (a predecessor tile never published): the view is void");
     return LG_OK;
 }
 

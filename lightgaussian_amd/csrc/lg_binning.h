@@ -318,15 +318,31 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 // entries, order inside a bucket arbitrary -- items are independent).  Empty tiles produce no item.  meta[0] = item count.
 // Runs as ONE EXTRA WORKGROUP of the forward blend (lg_blend_fwd, block index ntiles_pad): the ranges are final by then, and
 // the 10 us a lone workgroup needs for 8160 tiles hide behind the blend instead of standing in front of the backward.
-// It also tells the HOST that this view has tiles longer than hint_min entries: `long_hint` (may be NULL) is a word of pinned host
-// memory that the next forwards read to decide whether the parallel long-tile kernels are worth launching (lg_blend_fwd_seg).
+// It also lists the items of the tiles whose list goes through the parallel long-tile forward (par_work, meta[4] items;
+// lg_blend_fwd_seg / _scan / _rewalk): the lists longer than lg_par_min() -- a pure function of THIS view's device-side
+// numbers (long-tile mode of the call, S, instance count R, tile count), the same one the tile workgroups of lg_blend_fwd
+// evaluate to leave those lists alone.
+__device__ __forceinline__ uint32_t lg_par_min(int long_mode, int S, uint32_t R, int ntiles)
+{
+    // 0 = serial: every list is walked by lg_blend_fwd.  2 = every multi-segment list in parallel.  1 ("auto") = lists longer
+    // than two segments AND four times the mean list of the view: such a list is the forward's critical path (its serial walk
+    // outlasts everything else), shorter ones are not.  Measured (fwd+bwd views/s, heavy-tailed scene / 6 M Gaussians at
+    // 1600x1060): every multi-segment list 466 / 310; > 2 S 459 / 338; > 3 S 439 / 356; > 4 S 411 / 352; > 8 S 380 / 347;
+    // serial only 416 / 353.  With the mean-relative rule the dense scene (mean list 1200) sends nothing and the heavy-tailed
+    // one (mean 545, lists to 24 000) everything above 2180.
+    if (long_mode == 0) return 0u;
+    if (long_mode == 2) return (uint32_t)S;
+    const uint64_t mean4 = 4ull * (uint64_t)R / (uint64_t)max(ntiles, 1);
+    return max(2u * (uint32_t)S, (uint32_t)min(mean4, (uint64_t)(1u << 30)));
+}
+
 __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work,
                                                    uint32_t* __restrict__ meta, uint32_t* hist /* LDS [256] */,
-                                                   uint32_t* base /* LDS [257] */, uint32_t tid, uint32_t nthreads,
-                                                   uint32_t* long_hint, uint32_t hint_min)
+                                                   uint32_t* base /* LDS [258] */, uint32_t tid, uint32_t nthreads,
+                                                   uint2* __restrict__ par_work, uint32_t par_min)
 {
     if (tid < 256) hist[tid] = 0;
-    if (tid == 0) base[256] = 0;
+    if (tid == 0) { base[256] = 0; base[257] = 0; }
     __syncthreads();
     uint32_t longest = 0;
     for (int t = (int)tid; t < T; t += (int)nthreads) {
@@ -335,22 +351,27 @@ __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __
         for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S)
             atomicAdd(&hist[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u); // bucket 0 = longest
     }
-    if (longest > hint_min) atomicMax(&base[256], longest);
+    if (longest != 0u) atomicMax(&base[256], longest);
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; }
         meta[0] = acc;
-        meta[1] = base[256];                                    // longest list of the view when it exceeds hint_min, else 0
-        if (long_hint && base[256] != 0u) {
-            __hip_atomic_store(long_hint, base[256], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        meta[1] = base[256];                                    // longest list of the view
+        meta[2] = (uint32_t)S;                                  // checked by the backward (lg_blend_bwd, lg_preprocess_bwd)
+        meta[3] = par_min;
     }
     __syncthreads();
     for (int t = (int)tid; t < T; t += (int)nthreads) {
         const uint2 r = ranges[t];
+        const uint32_t n = r.y - r.x;
+        const bool par = par_min != 0u && n > par_min;
         uint32_t seg = 0;
-        for (uint32_t lo = 0, n = r.y - r.x; lo < n; lo += (uint32_t)S, seg++)
+        for (uint32_t lo = 0; lo < n; lo += (uint32_t)S, seg++) {
             work[atomicAdd(&base[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u)] = make_uint2((uint32_t)t, seg);
+            if (par) par_work[atomicAdd(&base[257], 1u)] = make_uint2((uint32_t)t, seg);
+        }
     }
+    __syncthreads();
+    if (tid == 0) meta[4] = base[257];
 }

@@ -119,13 +119,17 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
-             uint2* __restrict__ work, uint32_t* __restrict__ meta, uint32_t* long_hint, uint32_t hint_min, uint32_t par_min)
+             uint2* __restrict__ work, uint32_t* __restrict__ meta, uint2* __restrict__ par_work, const uint32_t* __restrict__ counters,
+             int long_mode)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
+    // view's own numbers (counters[3] = its instance count), evaluated identically by every workgroup
+    const uint32_t par_min = lg_par_min(long_mode, S, counters[3], ntiles);
     if (blockIdx.x == (uint32_t)ntiles_pad) {
         // the one workgroup past the tiles: work list of the backward blend (lg_binning.h), overlapped with the blending
         uint32_t* scratch = reinterpret_cast<uint32_t*>(&q0[0][0]);
-        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, long_hint, hint_min);
+        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, par_work, par_min);
         return;
     }
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
@@ -257,9 +261,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 // re-walk); transmittances are regrouped products, so images agree to float rounding, not bit for bit -- the canonical
 // (count / EXACT) path keeps the serial walk.  Which lists: the free-running pass evaluates every entry for every pixel (the
 // serial walk stops when its 64 pixels are saturated) and costs three more launches, so it pays only for lists whose serial
-// walk would BE the forward's critical path.  "auto" (lg_api.hip) takes lists longer than two segments and four times the
-// view's mean list, and only once an earlier view of the process has reported one (pinned hint word, lg_work_order_body): the
-// uniform benchmark scene never launches these kernels; lg_set_long_tile_mode(2) sends every multi-segment list (tests).
+// walk would BE the forward's critical path.  "auto" (the default; lg_par_min, lg_binning.h) takes lists longer than two
+// segments and four times the view's mean list -- decided on the device from this view's own instance count, no history: the
+// three kernels are launched for every hardware-exp colour forward as small persistent grids over the par_work list that the
+// forward's work-list workgroup leaves (meta[4] items: zero on the uniform benchmark scene, where each launch is one scalar
+// load per workgroup); LG_FLAG_LONG_PARALLEL sends every multi-segment list (tests), LG_FLAG_LONG_SERIAL none.
 __device__ __forceinline__ void fwd_free(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
                                          float& C0, float& C1, float& C2, uint32_t& last, uint32_t rel)
 {
@@ -309,35 +315,37 @@ __device__ __forceinline__ void lg_walk_block(uint32_t list0, uint32_t lo, uint3
     }
 }
 
+#define LG_PAR_GRID 1024   // persistent workgroups of the three long-tile kernels (they loop over the par_work items)
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_seg(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                  const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,
                  uint32_t* __restrict__ ckpt_last)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
-    if (blockIdx.x >= meta[0]) return;
-    const uint2 item = work[blockIdx.x];
-    const int tile = (int)item.x;
-    const uint2 range = ranges[tile];
-    const uint32_t n = range.y - range.x;
-    if (n <= par_min) return;                                      // (par_min >= S) a shorter list: lg_blend_fwd rendered it
+    const uint32_t nitems = meta[4];
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    const int tx = tile % gx, ty = tile / gx;
-    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
-    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint32_t lo = item.y * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t last = 0;
-    lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
-                  [&](const float4& a, const float4& b, const float4& c, uint32_t rel) { fwd_free(a, b, c, inside, pxf, pyf, T, C0, C1, C2, last, rel); },
-                  [&]() { return false; });
-    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
-    const size_t slot = ((size_t)2 * (range.x / (uint32_t)S) + item.y) * 256 + pix;
-    ckpt[slot] = make_float4(T, C0, C1, C2);
-    ckpt_last[slot] = last;
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint2 item = par_work[it];
+        const int tile = (int)item.x;
+        const uint2 range = ranges[tile];
+        const uint32_t n = range.y - range.x;
+        const int tx = tile % gx, ty = tile / gx;
+        const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+        const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const float pxf = (float)pxi, pyf = (float)pyi;
+        const uint32_t lo = item.y * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
+        float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+        uint32_t last = 0;
+        lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
+                      [&](const float4& a, const float4& b, const float4& c, uint32_t rel) { fwd_free(a, b, c, inside, pxf, pyf, T, C0, C1, C2, last, rel); },
+                      [&]() { return false; });
+        const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+        const size_t slot = ((size_t)2 * (range.x / (uint32_t)S) + item.y) * 256 + pix;
+        ckpt[slot] = make_float4(T, C0, C1, C2);
+        ckpt_last[slot] = last;
+    }
 }
 
 // pass 2: per long tile, per pixel: prefix products over the segments.  A pixel whose transmittance never comes near the
@@ -345,55 +353,56 @@ lg_blend_fwd_seg(int W, int H, int gx, int S, uint32_t par_min, const uint2* __r
 // the checkpoint slot of s*, s* itself in the last-contributor word of slot 0 -- for lg_blend_fwd_rewalk.
 #define LG_NO_SEG 0xFFFFFFFFu
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_scan(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                   const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   float4* __restrict__ ckpt, uint32_t* __restrict__ ckpt_last)
 {
-    if (blockIdx.x >= meta[0]) return;
-    const uint2 item = work[blockIdx.x];
-    if (item.y != 0u) return;                                       // one scan per tile: the work item of its first segment
-    const int tile = (int)item.x;
-    const uint2 range = ranges[tile];
-    const uint32_t n = range.y - range.x;
-    if (n <= par_min) return;
-    const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t nitems = meta[4];
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    const int tx = tile % gx, ty = tile / gx;
-    const int pxi = tx * LG_TILE + (wave & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (wave >> 1) * 8 + (int)(lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
-    float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-    uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t last = 0, sstar = LG_NO_SEG;
-    if (inside) {
-        for (uint32_t s = 0; s < nseg; s++) {
-            const float4 r = ck[(size_t)s * 256];
-            const uint32_t ll = cl[(size_t)s * 256];
-            const float Tend = T * r.x;
-            // would this pixel stop inside the segment?  (T P_s < 1e-4 up to the rounding of the regrouped product: the margin
-            // only sends a few more pixels through the exact re-walk)
-            if (!(Tend >= LG_T_MIN * 1.001f)) { sstar = s; break; }
-            const float in0 = T * r.y, in1 = T * r.z, in2 = T * r.w;
-            C0 += in0; C1 += in1; C2 += in2;
-            T = Tend;
-            last = ll ? ll : last;
-            ck[(size_t)s * 256] = make_float4(T, in0, in1, in2);   // what the backward starts segment s from
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint2 item = par_work[it];
+        if (item.y != 0u) continue;                                     // one scan per tile: the work item of its first segment
+        const int tile = (int)item.x;
+        const uint2 range = ranges[tile];
+        const uint32_t n = range.y - range.x;
+        const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+        const int tx = tile % gx, ty = tile / gx;
+        const int pxi = tx * LG_TILE + (wave & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (wave >> 1) * 8 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+        float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+        uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+        float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+        uint32_t last = 0, sstar = LG_NO_SEG;
+        if (inside) {
+            for (uint32_t s = 0; s < nseg; s++) {
+                const float4 r = ck[(size_t)s * 256];
+                const uint32_t ll = cl[(size_t)s * 256];
+                const float Tend = T * r.x;
+                // would this pixel stop inside the segment?  (T P_s < 1e-4 up to the rounding of the regrouped product: the margin
+                // only sends a few more pixels through the exact re-walk)
+                if (!(Tend >= LG_T_MIN * 1.001f)) { sstar = s; break; }
+                const float in0 = T * r.y, in1 = T * r.z, in2 = T * r.w;
+                C0 += in0; C1 += in1; C2 += in2;
+                T = Tend;
+                last = ll ? ll : last;
+                ck[(size_t)s * 256] = make_float4(T, in0, in1, in2);   // what the backward starts segment s from
+            }
+            if (sstar == LG_NO_SEG) {
+                const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+                final_T[pid] = T;
+                n_contrib[pid] = last;
+                out_color[pid] = fmaf(T, bg[0], C0);
+                out_color[HW + pid] = fmaf(T, bg[1], C1);
+                out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+            } else {
+                ck[(size_t)sstar * 256] = make_float4(T, C0, C1, C2);
+                if (sstar > 0u) cl[(size_t)sstar * 256] = last;       // (s* = 0: nothing contributed before it)
+            }
         }
-        if (sstar == LG_NO_SEG) {
-            const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
-            final_T[pid] = T;
-            n_contrib[pid] = last;
-            out_color[pid] = fmaf(T, bg[0], C0);
-            out_color[HW + pid] = fmaf(T, bg[1], C1);
-            out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
-        } else {
-            ck[(size_t)sstar * 256] = make_float4(T, C0, C1, C2);
-            if (sstar > 0u) cl[(size_t)sstar * 256] = last;       // (s* = 0: nothing contributed before it)
-        }
+        cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
     }
-    cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
 }
 
 // pass 3: one workgroup per (long tile, segment) again; a wave has work only if one of its pixels was parked at this segment.
@@ -401,66 +410,67 @@ lg_blend_fwd_scan(int W, int H, int gx, int S, uint32_t par_min, const uint2* __
 // contributor index -- and are finished here.  (A parked pixel that turns out not to stop inside its segment -- the margin of
 // the scan -- simply keeps walking the following segments the same way: rare, and exact.)
 __global__ void __launch_bounds__(256)
-lg_blend_fwd_rewalk(int W, int H, int gx, int S, uint32_t par_min, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+lg_blend_fwd_rewalk(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                     const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
                     float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ ckpt,
                     const uint32_t* __restrict__ ckpt_last)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
-    if (blockIdx.x >= meta[0]) return;
-    const uint2 item = work[blockIdx.x];
-    const int tile = (int)item.x;
-    const uint2 range = ranges[tile];
-    const uint32_t n = range.y - range.x;
-    if (n <= par_min) return;
-    const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t nitems = meta[4];
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    const int tx = tile % gx, ty = tile / gx;
-    const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
-    const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
-    float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-    const uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-    const bool mine = inside && cl[0] == item.y;                    // parked at this segment
-    if (__ballot(mine) == 0) return;
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t last = 0;
-    if (mine) {
-        const float4 st = ck[(size_t)item.y * 256];
-        T = st.x; C0 = st.y; C1 = st.z; C2 = st.w;
-        last = item.y > 0u ? cl[(size_t)item.y * 256] : 0u;
-    }
-    bool dn = !mine;
-    uint32_t cur = item.y, mynext = item.y;                         // mynext: first segment this pixel did not enter
-    for (; cur < nseg && __ballot(!dn) != 0; cur++) {              // wave-uniform
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        uint32_t ls = 0;
-        const bool entered = !dn;
-        const uint32_t lo = cur * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
-        lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
-                      [&](const float4& a, const float4& b, const float4& c, uint32_t rel) {
-                          float alpha = 0.0f, w = 0.0f;
-                          (void)fwd_pair<false, true>(a, b, c, !dn, pxf, pyf, T, s0, s1, s2, dn, ls, rel, alpha, w);
-                      },
-                      [&]() { return __ballot(!dn) == 0; });
-        if (entered) {
-            C0 += s0; C1 += s1; C2 += s2;
-            last = ls ? ls : last;
-            ck[(size_t)cur * 256] = make_float4(T, s0, s1, s2);
-            mynext = cur + 1u;
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint2 item = par_work[it];
+        const int tile = (int)item.x;
+        const uint2 range = ranges[tile];
+        const uint32_t n = range.y - range.x;
+        const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+        const int tx = tile % gx, ty = tile / gx;
+        const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+        const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const float pxf = (float)pxi, pyf = (float)pyi;
+        const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+        float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+        const uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+        const bool mine = inside && cl[0] == item.y;                    // parked at this segment
+        if (__ballot(mine) == 0) continue;
+        float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+        uint32_t last = 0;
+        if (mine) {
+            const float4 st = ck[(size_t)item.y * 256];
+            T = st.x; C0 = st.y; C1 = st.z; C2 = st.w;
+            last = item.y > 0u ? cl[(size_t)item.y * 256] : 0u;
         }
-    }
-    if (mine) {
-        for (uint32_t j = mynext; j < nseg; j++) ck[(size_t)j * 256] = make_float4(T, 0.0f, 0.0f, 0.0f);   // segments never entered
-        const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
-        final_T[pid] = T;
-        n_contrib[pid] = last;
-        out_color[pid] = fmaf(T, bg[0], C0);
-        out_color[HW + pid] = fmaf(T, bg[1], C1);
-        out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+        bool dn = !mine;
+        uint32_t cur = item.y, mynext = item.y;                         // mynext: first segment this pixel did not enter
+        for (; cur < nseg && __ballot(!dn) != 0; cur++) {              // wave-uniform
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+            uint32_t ls = 0;
+            const bool entered = !dn;
+            const uint32_t lo = cur * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
+            lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
+                          [&](const float4& a, const float4& b, const float4& c, uint32_t rel) {
+                              float alpha = 0.0f, w = 0.0f;
+                              (void)fwd_pair<false, true>(a, b, c, !dn, pxf, pyf, T, s0, s1, s2, dn, ls, rel, alpha, w);
+                          },
+                          [&]() { return __ballot(!dn) == 0; });
+            if (entered) {
+                C0 += s0; C1 += s1; C2 += s2;
+                last = ls ? ls : last;
+                ck[(size_t)cur * 256] = make_float4(T, s0, s1, s2);
+                mynext = cur + 1u;
+            }
+        }
+        if (mine) {
+            for (uint32_t j = mynext; j < nseg; j++) ck[(size_t)j * 256] = make_float4(T, 0.0f, 0.0f, 0.0f);   // segments never entered
+            const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+            final_T[pid] = T;
+            n_contrib[pid] = last;
+            out_color[pid] = fmaf(T, bg[0], C0);
+            out_color[HW + pid] = fmaf(T, bg[1], C1);
+            out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+        }
     }
 }
 
@@ -658,6 +668,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
 #endif
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
+    if (meta[2] != (uint32_t)S) return;           // another segment length than the forward's (see lg_preprocess_bwd)
     const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
     const int tile = (int)item.x;
     const uint32_t lane = threadIdx.x;

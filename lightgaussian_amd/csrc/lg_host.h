@@ -148,48 +148,24 @@ static ImgView carve_img(void* base, int W, int H)
 // Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
 // offsets for both key formats.  There is no separate id list and no slot list: the id is the low field of the sorted
 // key, and the pre-sort slot (row address of the backward) is recomputed from the Gaussian's tile rectangle (tinfo).
-// Long per-tile lists (real captures: tens of thousands of entries on a few tiles) are cut into SEGMENTS of g_segment
-// entries: the forward leaves one checkpoint record per pixel at the end of every segment of such a tile, and the backward
-// runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry tile becomes ten independent work items
-// instead of one 4 ms serial chain.  Tiles with at most one segment (all of the uniform benchmark scene) never touch the
-// checkpoints.  Process-wide so that the buffer sizes stay functions of (R, W, H); must not change between a forward and
-// its backward.  1024 by measurement: in a dense pile every entry touches all four 8x8 blocks of the tile, and a 2048-entry
-// segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of the uniform benchmark
-// scene stay below 1024.  lg_set_segment_length() exists for the tests (64 / 128 exercise the machinery on small scenes).
-static std::atomic<int> g_segment{1024};
-// Long tiles of the hardware-exp colour forward: 0 = serial walk inside lg_blend_fwd; 2 = every multi-segment list through the
-// parallel kernels (lg_blend_fwd_seg / _scan / _rewalk); 1 (default) = lists longer than two segments and four times the view's
-// mean list through them, once a view of this process has reported such a list through the pinned hint word (the uniform
-// benchmark scene never does and never pays the three extra launches).
-static std::atomic<int> g_long_mode{1};
-static uint32_t* g_long_hint = nullptr;      // pinned host word, written by the device (lg_work_order_body), read by the host
-static std::once_flag g_long_hint_once;
-static uint32_t* long_hint_word()
-{
-    std::call_once(g_long_hint_once, [] {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) { memset(p, 0, 64); g_long_hint = (uint32_t*)p; }
-    });
-    return g_long_hint;
-}
-extern "C" int lg_set_long_tile_mode(int32_t mode)
-{
-    const int prev = g_long_mode.load();
-    if (mode >= 0 && mode <= 2) g_long_mode.store(mode);
-    if (mode == 1 && long_hint_word()) *(volatile uint32_t*)long_hint_word() = 0u;   // "auto" starts from a clean hint
-    return prev;
-}
-extern "C" int lg_set_segment_length(int32_t entries)
-{
-    const int prev = g_segment.load();
-    if (entries >= 64 && entries % 64 == 0) g_segment.store(entries);
-    return prev;
-}
+// Long per-tile lists (real captures: tens of thousands of entries on a few tiles) are cut into SEGMENTS of S entries
+// (lg_view.segment_length, default LG_DEFAULT_SEGMENT): the forward leaves one checkpoint record per pixel at the end of every
+// segment of such a tile, and the backward runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry
+// tile becomes ten independent work items instead of one 4 ms serial chain.  Tiles with at most one segment (all of the
+// uniform benchmark scene) never touch the checkpoints.  S is part of the VIEW (the caller passes the same lg_view to the
+// forward and to its backward; the forward also stores it in meta[2] and the backward kernels refuse to run on a mismatch):
+// the library keeps no state of its own.  1024 by measurement: in a dense pile every entry touches all four 8x8 blocks of the
+// tile, and a 2048-entry segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of
+// the uniform benchmark scene stay below 1024.  64 / 128 exercise the machinery on small scenes (tests).
+#define LG_DEFAULT_SEGMENT 1024
+static inline int lg_segment_of(const lg_view* v) { return v->segment_length > 0 ? v->segment_length : LG_DEFAULT_SEGMENT; }
 
 struct BinView {
     uint2* ranges;                  // [tiles]
     uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
-    uint32_t* meta;                 // [16] 0 = number of work items (lg_work_order)
+    uint2* par_work;                // [tiles + R / S + 1] the items of the tiles whose list goes through the parallel long-tile forward
+    uint32_t* meta;                 // [16] 0 = number of work items, 1 = longest list of the view, 2 = S, 3 = par_min of the view
+                                    //      (0 = none), 4 = number of par_work items (all written by lg_work_order_body)
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
     uint32_t* ckpt_last;            // [2 (R / S + 1)][256] last contributing list position per (segment, pixel): pass 1 -> join of
                                     //     the parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk)
@@ -206,16 +182,17 @@ static int bits_for(uint32_t n) // smallest b with 2^b >= n
     while (b < 32 && (1ull << b) < n) b++;
     return b;
 }
-static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
+static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed, int seg)
 {
     BinView v; memset(&v, 0, sizeof(v)); size_t off = 0; char* p = (char*)base;
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     size_t n = (size_t)(R > 0 ? R : 1);
     const int gx = (W + LG_TILE - 1) / LG_TILE, gy = (H + LG_TILE - 1) / LG_TILE;
-    const size_t S = (size_t)g_segment.load();
+    const size_t S = (size_t)(seg > 0 ? seg : LG_DEFAULT_SEGMENT);
     v.ranges = (uint2*)take((size_t)gx * gy * 8);
+    v.meta = (uint32_t*)take(64);                 // before anything whose size depends on S: the backward finds meta[2] (the forward's S) whatever S it was handed
     v.work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
-    v.meta = (uint32_t*)take(64);
+    v.par_work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
     v.ckpt = (float4*)take(2 * (n / S + 1) * 256 * 16);
     v.ckpt_last = (uint32_t*)take(2 * (n / S + 1) * 256 * 4);
     v.entries = (uint64_t*)take(n * 8);
@@ -238,9 +215,10 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed)
 
 extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
 extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
-extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H)
+extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H, int32_t segment_length)
 {
-    const size_t a = carve_bin(nullptr, R, W, H, true).total, b = carve_bin(nullptr, R, W, H, false).total;
+    if (segment_length != 0 && (segment_length < 64 || segment_length % 64 != 0)) return 0;   // (lg_forward rejects such a view)
+    const size_t a = carve_bin(nullptr, R, W, H, true, segment_length).total, b = carve_bin(nullptr, R, W, H, false, segment_length).total;
     return a > b ? a : b; // upper bound over both key formats
 }
 extern "C" size_t lg_backward_scratch_bytes(int32_t N, int64_t R)

@@ -228,7 +228,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                   const int32_t* __restrict__ radii, const float4* __restrict__ rec,
-                  const uint32_t* __restrict__ counters, const uint32_t* __restrict__ touched,
+                  const uint32_t* __restrict__ counters, const uint32_t* __restrict__ meta, uint32_t S, const uint32_t* __restrict__ touched,
                   const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                   float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
@@ -242,8 +242,10 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    // counters[0] != 0: the forward aborted this view on the device (lg_forward_bounded overflow); there are no rows
-    const bool vis = (i < N) && radii[i] > 0 && counters[0] == 0u;
+    // counters[0] != 0: the forward aborted this view on the device (lg_forward_bounded overflow); there are no rows.
+    // meta[2] != S: this backward was given another segment length than the forward that filled the buffers (lg_view.segment_length
+    // must match): lg_blend_bwd refused to run, there are no rows either -- zero gradients, and LG_FLAG_DEBUG reports it
+    const bool vis = (i < N) && radii[i] > 0 && counters[0] == 0u && meta[2] == S;
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;
     const int rowf = split ? 3 * (M - 1) : 3 * M;

@@ -38,6 +38,10 @@
 #define LG_SORT_FLAG_AGG 1u
 #define LG_SORT_FLAG_PREFIX 2u
 #define LG_SORT_VALUE_MASK 0x3FFFFFFFu
+#define LG_ABORT_SORT 4u     // bit of the view's abort word (counters[0]) / of the stand-alone sort's error word
+#ifndef LG_SORT_POLL_BUDGET
+#define LG_SORT_POLL_BUDGET (1u << 18)
+#endif
 static_assert(LG_SORT_BLOCK >= 256 && LG_SORT_BLOCK % 64 == 0, "one thread per digit needs >= 256 threads");
 static_assert(LG_SORT_ITEMS * 64 < 65536 && LG_SORT_TILE < 65536, "16-bit LDS counters");
 
@@ -103,7 +107,8 @@ __device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { (void)__h
 #endif
 __global__ void __launch_bounds__(LG_SORT_BLOCK) LG_SORT_OCC
 lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ counters, uint32_t n_arg,
-                 int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* ticket, uint32_t* states)
+                 int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* ticket, uint32_t* states, uint32_t* err,
+                 uint32_t poll_budget)
 {
     __shared__ uint64_t stage[LG_SORT_TILE];
     __shared__ unsigned short wcnt[LG_SORT_WAVES][256];
@@ -196,9 +201,10 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
             // (~30 at 500 tiles, ~1 us each: most of a pass).  Reading LG_SORT_WINDOW predecessors per round trip (independent
             // loads, all in flight) cuts that to ~sqrt(2 * tiles / window).  States are consumed nearest-first; a zero
             // (unpublished) state is re-polled alone.  (The TOTAL number of polls of a thread is bounded: a predecessor
-            // always publishes -- ticket order -- so the bound is never reached; it turns a would-be hang of the device into a
-            // wrong result that the tests catch.)
-            uint32_t budget = 1u << 18;
+            // always publishes -- ticket order -- so the bound is never reached; if it ever is, the would-be hang of the device
+            // becomes a REPORTED failure: bit LG_ABORT_SORT of *err (the view's abort word counters[0]: lg_tile_ranges and the
+            // blend kernels then leave the view empty, the status words / LG_FLAG_DEBUG / lg_view_status() surface LG_ERR_DEVICE).)
+            uint32_t budget = poll_budget;
             int64_t b = (int64_t)tile - 1;
             bool found = false;
             while (b >= 0 && !found) {
@@ -216,6 +222,7 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
                             sv = lg_ld_state(&states[(size_t)(b - k) * 256 + tid]);
                         }
                         excl += sv & LG_SORT_VALUE_MASK;
+                        if ((sv >> 30) == 0u) atomicOr(err, LG_ABORT_SORT);       // budget exhausted: this sort's result is void
                         found = (sv >> 30) == LG_SORT_FLAG_PREFIX || budget == 0u;
                     }
                 }
@@ -249,8 +256,10 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
 // temp == NULL: size query.  hist_ready: the caller already accumulated the digit histograms into temp (+ L.hist_off) AFTER
 // clearing lg_sort_clear_bytes() bytes of temp -- the rasterizer's K3 does; otherwise this function clears and counts.
 // counters: optional device words {[0] abort flag, [3] key count} (see lg_onesweep_pass); n = capacity = upper bound of the count.
+// err: device word that receives LG_ABORT_SORT when a look-back gives up (NULL: counters[0], or -- without counters -- word 15 of
+// the ticket block, which lg_debug_sort_keys reads back).
 static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, uint32_t n, int begin_bit,
-                               int end_bit, const uint32_t* counters, bool hist_ready, hipStream_t stream)
+                               int end_bit, uint32_t* counters, bool hist_ready, hipStream_t stream, uint32_t poll_budget = LG_SORT_POLL_BUDGET)
 {
     const LgSortLayout L = lg_sort_layout(n);
     if (temp == nullptr) { temp_bytes = L.total; return hipSuccess; }
@@ -274,7 +283,8 @@ static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k
         const int bit = begin_bit + 8 * p, nb = std::min(8, end_bit - bit);
         uint64_t* dst = to_output ? keys_out : keys_tmp;
         lg_onesweep_pass<<<L.tiles, LG_SORT_BLOCK, 0, stream>>>(src, dst, counters, n, bit, nb, hist + (size_t)p * 256, tickets + p,
-                                                                 states + (size_t)p * L.tiles * 256);
+                                                                 states + (size_t)p * L.tiles * 256, counters ? counters : tickets + 15,
+                                                                 poll_budget);
         src = dst;
         to_output = !to_output;
     }

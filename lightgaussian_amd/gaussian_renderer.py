@@ -84,23 +84,25 @@ def _has_reference_getters(pc):
             and pc._features_rest.dim() == 3 and pc._features_dc.dim() == 3 and pc._features_dc.shape[1] == 1)
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *, options=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.
+    options (keyword-only extension): per-call overrides of the rasterizer knobs (rasterizer.set_option), e.g.
+    {"sync_free": True}; the reference's six positional parameters are unchanged.
 
     With option fuse_getters (default True) and a GaussianModel carrying the reference's own activations, the getters
     are evaluated INSIDE the kernels from the raw parameters (render_fused: no torch.cat of the SH tensors, no
     activation kernels; same values to ~1e-7, gradients land on the raw parameters exactly as autograd would route
     them).  set_option("fuse_getters", False) restores the reference's literal call pattern."""
-    if (_rasterizer._OPTIONS["fuse_getters"] and override_color is None and not pipe.convert_SHs_python
+    if (_rasterizer.resolve_options(options)["fuse_getters"] and override_color is None and not pipe.convert_SHs_python
             and not pipe.compute_cov3D_python and _has_reference_getters(pc)):
-        return render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
-    return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+        return render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, options=options)
+    return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, options)
 
 
-def _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+def _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, options=None):
     """gaussian_renderer/__init__.py:22-124 literally: getters in torch, activated tensors into the rasterizer."""
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False), options=options)
     means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp = _inputs(
         viewpoint_camera, pc, pipe, scaling_modifier, override_color)
     rendered_image, radii = rasterizer(
@@ -110,10 +112,11 @@ def _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, 
             "radii": radii}
 
 
-def count_render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
-    """render() + per-Gaussian hit count and Global Significance score (f_count=True)."""
+def count_render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *, options=None):
+    """render() + per-Gaussian hit count and Global Significance score (f_count=True).  options: as for render(), e.g.
+    {"skip_color_in_count": True} for passes that only consume the counts / scores."""
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, True))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, True), options=options)
     means3D, opacity, scales, rotations, cov3D_precomp, shs, colors_precomp = _inputs(
         viewpoint_camera, pc, pipe, scaling_modifier, override_color)
     gaussians_count, important_score, rendered_image, radii = rasterizer(
@@ -123,17 +126,17 @@ def count_render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mod
             "radii": radii, "gaussians_count": gaussians_count, "important_score": important_score}
 
 
-def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, *, options=None):
     """render() with the getters fused into the kernels (opt-in extension -- the reference's
     render() evaluates exp/sigmoid/normalize and cat(_features_dc, _features_rest) in torch on every call, which at
     3M Gaussians costs as much HBM traffic as the whole rasterizer).  Reads GaussianModel's raw tensors
     (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation: scene/gaussian_model.py:45-60) directly; same
     result dict, gradients land on the raw parameters.  Falls back to render() for the Python-side alternates."""
     if override_color is not None or pipe.convert_SHs_python or pipe.compute_cov3D_python:
-        return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+        return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, options)
     screenspace_points = _screenspace_points(pc)
     rs = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False)
     rendered_image, radii = rasterize_gaussians_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
-                                                    pc._scaling, pc._rotation, rs)
+                                                    pc._scaling, pc._rotation, rs, options)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}

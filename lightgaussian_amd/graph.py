@@ -80,12 +80,10 @@ class GraphedStep:
         if dev.type != "cuda":
             raise RuntimeError("GraphedStep needs the model on a HIP device (torch 'cuda'); there is no CPU path")
         static_cam, static_gt = _StaticCam(cam, dev), gt.detach().to(dev, torch.float32).clone()
-        saved = _rast._OPTIONS["sync_free"]
-        try:
-            _rast.set_option("sync_free", "validated")
+        batch = _rast.PendingBatch()
+        with _rast.options(sync_free="validated"):
             self._body(static_cam, static_gt)                     # learns the binning capacity of this shape (exact path first)
-            _rast.set_option("sync_free", True)
-            _rast.pending_status()
+        with _rast.options(sync_free=True, pending=batch):
             # The step runs on fresh autograd LEAVES that share the parameters' storage (parallel._LeafView), one set for the
             # warm-up and one for the capture: an AccumulateGrad node remembers the stream it was created on, and the
             # parameters' own nodes -- alive for as long as the caller holds any tensor of an earlier eager step -- were
@@ -98,25 +96,19 @@ class GraphedStep:
             with torch.cuda.stream(side):                         # warm-up off the capture stream, as graph capture asks for
                 self._body(static_cam, static_gt, _LeafView(self.pc))
             torch.cuda.current_stream(dev).wait_stream(side)
-            _rast.pending_status()
+            batch.resolve()
             view = _LeafView(self.pc)                             # its .grad tensors are allocated inside the graph's pool
             status = torch.full((4,), -1, dtype=torch.int32).pin_memory()   # written by K2 of every replay, polled by the host
             graph = torch.cuda.CUDAGraph()
-            _rast._STATUS_OVERRIDE = status
-            try:
+            with _rast.options(status_override=status):
                 with torch.cuda.graph(graph):
                     static_loss = self._body(static_cam, static_gt, view)
-            finally:
-                _rast._STATUS_OVERRIDE = None
-            with _rast._CAP_LOCK:
-                pend = list(_rast._PENDING)
-                _rast._PENDING.clear()
+            with batch.lock:
+                pend, batch.items = batch.items, []
             bounded = [p for p in pend if p[0] is status]
             if len(bounded) != 1:
                 raise RuntimeError("GraphedStep: the captured step did not go through the capacity-bounded forward "
                                    "(prefiltered rasterizer settings or the pair key format have no bounded form)")
-        finally:
-            _rast.set_option("sync_free", saved)
         self.captures += 1
         grads = [getattr(view, n).grad for n in _PARAMS]          # static: every replay writes these tensors
         for n, t in zip(_PARAMS, grads):
@@ -151,12 +143,8 @@ class GraphedStep:
         return static_loss
 
     def _eager(self, cam, gt):
-        saved = _rast._OPTIONS["sync_free"]
-        try:
-            _rast.set_option("sync_free", "validated")
+        with _rast.options(sync_free="validated"):
             return self._body(cam, gt)
-        finally:
-            _rast.set_option("sync_free", saved)
 
     def _model_id(self):
         """The graph holds the parameters' addresses: any new storage (prune_points, densification, load_ply) invalidates it."""
@@ -186,7 +174,7 @@ class GraphedStep:
         flags, _v, _d, R = [int(x) & 0xFFFFFFFF for x in status.tolist()]
         with _rast._CAP_LOCK:
             _rast._CAPACITY[cap_key] = -1 if (flags & 2) else max(_rast._CAPACITY.get(cap_key, 0),
-                                                                  int(R * _rast._OPTIONS["capacity_margin"]) + 4096)
+                                                                  int(R * _rast.resolve_options()["capacity_margin"]) + 4096)
         del self._graphs[key]
         self.repairs += 1
         return self._eager(cam, gt)

@@ -24,7 +24,7 @@ from . import rasterizer as _rast
 
 def _flags():
     f = 0
-    if _rast._OPTIONS.get("profile"):
+    if _rast.resolve_options().get("profile"):
         f |= _lib.FLAG_PROFILE
     return f
 
@@ -45,7 +45,7 @@ class _L1SSIM(torch.autograd.Function):
         ctx.save_for_backward(img, gt, state)
         ctx.dims = (planes, H, W)
         ctx.token = {"consumed": False}      # shared with the memo of _both(): a graph that ran backward is not handed out again
-        _L1SSIM.last_token = ctx.token
+        _memo.token = ctx.token              # forward runs on the caller's thread: handed to _both() through ITS thread-local slot
         return out[0], out[1]
 
     @staticmethod
@@ -92,8 +92,10 @@ def _both(img, gt, last_use=False):
                 _memo.last = None
             return l1, ss
     a, b = _prep(img, gt)
+    _memo.token = None
     l1, ss = _L1SSIM.apply(a, b)
-    token = _L1SSIM.last_token if (torch.is_grad_enabled() and a.requires_grad) else {"consumed": False}
+    token = getattr(_memo, "token", None) if (torch.is_grad_enabled() and a.requires_grad) else None
+    token = token if token is not None else {"consumed": False}
     _memo.last = None if last_use else (weakref.ref(img), img._version, weakref.ref(gt), gt._version, l1, ss,
                                         torch.is_grad_enabled(), token)
     return l1, ss

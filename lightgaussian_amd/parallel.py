@@ -125,9 +125,20 @@ class OverlappedGradAllReduce:
         self.pending = []
         out = dict(self.grads)
         if model is not None:
+            # The reduced buffers must replace what autograd put into the leaves.  That only works when the hook saw the RAW
+            # parameters (gaussian_renderer.render with fused getters: keys _xyz, _features_dc, ...).  On the literal getter
+            # pattern the rasterizer's gradients are those of the ACTIVATED tensors (means3D, shs, opacities, ...): autograd has
+            # already chained the unreduced values into the leaves, and installing nothing would leave every rank training on
+            # its own local gradients, silently.  Refuse instead.
+            foreign = [n for n in out if not isinstance(getattr(model, n, None), torch.Tensor)]
+            if foreign:
+                raise RuntimeError(
+                    "OverlappedGradAllReduce.finish(model): the backward produced gradients for " + ", ".join(sorted(foreign)) +
+                    ", which are not parameters of the model -- the step did not go through the fused raw-parameter path "
+                    "(fuse_getters off, convert_SHs_python / compute_cov3D_python, or a model without the reference's getters). "
+                    "The leaves hold UNREDUCED gradients; use allreduce_gradients(params) after backward() for such steps.")
             for name, g in out.items():
-                if hasattr(model, name):
-                    getattr(model, name).grad = g
+                getattr(model, name).grad = g
         return out
 
     def _unpack(self, flat, ts):
@@ -234,7 +245,7 @@ def backward_over_views(model, cameras, targets, pipe, background, loss_fn, rend
         loss.backward()
         return loss.detach()
 
-    def issue_all(views):
+    def issue_all(views, mode):
         losses = [None] * len(cameras)
         if host_threads:
             import threading
@@ -243,7 +254,7 @@ def backward_over_views(model, cameras, targets, pipe, background, loss_fn, rend
             def work(w):
                 try:
                     torch.cuda.set_device(dev)
-                    with torch.cuda.stream(pool[w]):
+                    with torch.cuda.stream(pool[w]), rasterizer.options(**mode):
                         pool[w].wait_stream(main)
                         for k in range(w, len(cameras), K):
                             losses[k] = one(w, k, views[w])
@@ -260,25 +271,22 @@ def backward_over_views(model, cameras, targets, pipe, background, loss_fn, rend
         else:
             for st in pool:
                 st.wait_stream(main)
-            for k in range(len(cameras)):
-                with torch.cuda.stream(pool[k % K]):
-                    losses[k] = one(k % K, k, views[k % K])
+            with rasterizer.options(**mode):
+                for k in range(len(cameras)):
+                    with torch.cuda.stream(pool[k % K]):
+                        losses[k] = one(k % K, k, views[k % K])
         for st in pool:
             main.wait_stream(st)
         return losses
 
-    prev = rasterizer._OPTIONS["sync_free"]
-    rasterizer.set_option("sync_free", not host_threads)
-    try:
-        rasterizer.pending_status()                       # forget forwards issued by earlier callers
+    # per-thread options and a status batch of this call's own: nothing is switched process-wide
+    batch = rasterizer.PendingBatch()
+    mode = {"sync_free": not host_threads, "pending": batch}
+    views = [_LeafView(model) for _ in range(K)]
+    losses = issue_all(views, mode)
+    if any(bad for _tag, bad in batch.resolve()):         # a view outgrew its capacity: redo the batch, exact forwards
         views = [_LeafView(model) for _ in range(K)]
-        losses = issue_all(views)
-        if rasterizer.pending_overflow():                 # a view outgrew its capacity: redo the batch, exact forwards
-            rasterizer.set_option("sync_free", False)
-            views = [_LeafView(model) for _ in range(K)]
-            losses = issue_all(views)
-    finally:
-        rasterizer.set_option("sync_free", prev)
+        losses = issue_all(views, {"sync_free": False})
     for n in _RAW:
         p = getattr(model, n)
         total = None

@@ -119,7 +119,7 @@ def prune_epilogue(gaussians, imp_list, v_pow, percent, fused_pow=False):
     mask = torch.empty(N, dtype=torch.uint8, device=dev)
     thresholds = torch.empty(2, dtype=torch.float32, device=dev)
     scratch = torch.empty(lib.lg_prune_scratch_bytes(N), dtype=torch.uint8, device=dev)
-    flags = _lib.FLAG_PROFILE if rasterizer._OPTIONS["profile"] else 0
+    flags = _lib.FLAG_PROFILE if rasterizer.resolve_options()["profile"] else 0
     _lib.check(lib.lg_prune_epilogue(N, scaling.data_ptr(), imp.data_ptr(), float(v_pow), float(percent), v_list.data_ptr(),
                                      mask.data_ptr(), thresholds.data_ptr(), scratch.data_ptr(), flags,
                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
@@ -197,8 +197,9 @@ class _ViewRunner:
     (per-stream partial sums, added at the end) and every view's score vector lands in its own row of the caller's buffer,
     to be summed in the reference's order afterwards."""
 
-    def __init__(self, gaussians, pipe, background, count_fn, N, streams, host_threads=False):
+    def __init__(self, gaussians, pipe, background, count_fn, N, streams, host_threads=False, options=None):
         self.g, self.pipe, self.bg, self.count_fn, self.N = gaussians, pipe, background, count_fn, N
+        self.options = dict(options or {})     # rasterizer options of every forward this runner issues (thread-local: rasterizer.options)
         self.dev = gaussians.get_xyz.device
         self.streams = max(1, int(streams)) if self.dev.type == "cuda" else 1
         self.host_threads = host_threads
@@ -215,8 +216,9 @@ class _ViewRunner:
         nv = len(views)
         if nv == 0:
             return
+        from . import rasterizer
         if self.streams == 1 or nv == 1:
-            with torch.no_grad():
+            with torch.no_grad(), rasterizer.options(**self.options):
                 for k in range(nv):
                     self._one(views[k], 0, rows, k)
             return
@@ -229,7 +231,7 @@ class _ViewRunner:
             def work(w):
                 try:
                     torch.cuda.set_device(self.dev)
-                    with torch.cuda.stream(self.pool[w]), torch.no_grad():
+                    with torch.cuda.stream(self.pool[w]), torch.no_grad(), rasterizer.options(**self.options):
                         self.pool[w].wait_stream(main)    # frozen getters / the running sum were produced on `main`
                         for k in range(w, nv, K):
                             self._one(views[k], w, rows, k)
@@ -246,28 +248,24 @@ class _ViewRunner:
             for st in self.pool[:K]:
                 main.wait_stream(st)
             return
-        from . import rasterizer
-        prev = rasterizer._OPTIONS["sync_free"]
-        rasterizer.set_option("sync_free", True)
-        try:
-            rasterizer.pending_status()                   # forget forwards issued by earlier callers
-            for st in self.pool[:K]:
-                st.wait_stream(main)
-            with torch.no_grad():
-                for k in range(nv):
-                    with torch.cuda.stream(self.pool[k % K]):
-                        self._one(views[k], k % K, rows, k)
-            for st in self.pool[:K]:
-                main.wait_stream(st)
-            redo = rasterizer.pending_status()            # ONE host sync per block of views
-        finally:
-            rasterizer.set_option("sync_free", prev)
-        if len(redo) == nv and any(redo):
+        # one host thread, sync-free forwards: the options apply to THIS thread only and the status words of these views are
+        # collected in a batch of their own, tagged with the view index -- whatever else the process renders meanwhile (another
+        # thread in render(), a count_fn that issues several forwards or none) cannot be mistaken for one of them
+        batch = rasterizer.PendingBatch()
+        for st in self.pool[:K]:
+            st.wait_stream(main)
+        with torch.no_grad(), rasterizer.options(**dict(self.options, sync_free=True, pending=batch)):
+            for k in range(nv):
+                with torch.cuda.stream(self.pool[k % K]), rasterizer.options(tag=k):
+                    self._one(views[k], k % K, rows, k)
+        for st in self.pool[:K]:
+            main.wait_stream(st)
+        redo = sorted({tag for tag, bad in batch.resolve() if bad})     # ONE host sync per block of views
+        if redo:
             # an abandoned view added zeros to the counts and wrote a zero score row: render it again, exact forward
-            with torch.no_grad():
-                for k in range(nv):
-                    if redo[k]:
-                        self._one(views[k], 0, rows, k)
+            with torch.no_grad(), rasterizer.options(**dict(self.options, sync_free=False)):
+                for k in redo:
+                    self._one(views[k], 0, rows, k)
 
     def count_sum(self):
         total = self.partial[0]
@@ -308,17 +306,14 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
              O(N); the first version of this function held all V score vectors, O(V * N)).
     Measured at C3 on one MI355X (identical results): round 1, a host thread per stream: streams 1 -> 1158, 2 -> 1061, 3 -> 1341,
     4 -> 1326 views/s; round 2, one host thread: 3 -> 1540, 4 -> 1579, 6 -> 1513 (heavy-tailed scene: 1336 / 1412 / 1299)."""
-    from . import rasterizer
-    prev = rasterizer._OPTIONS["skip_color_in_count"]
-    rasterizer.set_option("skip_color_in_count", True)   # the pass discards the images: do not read 192 B of SH per Gaussian per view
-    try:
-        return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, max(1, int(block)),
-                                   local_only, host_threads)
-    finally:
-        rasterizer.set_option("skip_color_in_count", prev)
+    # the pass discards the images: its forwards do not read 192 B of SH per Gaussian per view (a per-call option of the
+    # forwards THIS pass issues -- the process defaults are not touched, other threads render as before)
+    return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, max(1, int(block)),
+                               local_only, host_threads, {"skip_color_in_count": True})
 
 
-def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, block, local_only, host_threads):
+def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, block, local_only, host_threads,
+                        options=None):
     distributed = dist.is_available() and dist.is_initialized() and not local_only
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
@@ -331,7 +326,7 @@ def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_f
     N = gaussians.get_xyz.shape[0]
     dev = gaussians.get_xyz.device
     f32 = dict(dtype=torch.float32, device=dev)
-    runner = _ViewRunner(gaussians, pipe, background, count_fn, N, streams, host_threads)
+    runner = _ViewRunner(gaussians, pipe, background, count_fn, N, streams, host_threads, options)
     if world == 1 and not (distributed and force_collectives):
         if V == 0:
             raise IndexError("pop from empty list")     # what the reference's viewpoint_stack.pop() raises

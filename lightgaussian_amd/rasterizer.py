@@ -39,13 +39,29 @@ class GaussianRasterizationSettings(NamedTuple):
     f_count: bool = False
 
 
-# process-wide knobs that are not part of the reference API
+# Knobs that are not part of the reference API.  _OPTIONS holds the PROCESS DEFAULTS (set_option); every forward takes a
+# snapshot -- defaults, then the calling thread's `with options(...)` blocks, then the call's own `options=` argument -- and the
+# snapshot travels with the call (lg_view.flags / lg_view.segment_length) and into its backward.  Library code never mutates
+# the defaults: prune_list_sharded, backward_over_views, GraphedStep pass what they need per call / per thread.
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
-            "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25}
+            "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
+            "segment_length": 0, "long_tiles": "auto"}
+_PER_CALL_ONLY = ("pending", "tag", "status_override")
+_LONG_TILES = ("serial", "auto", "parallel")
+_tls = threading.local()
+
+
+def _validate(name, value):
+    if name == "long_tiles" and value not in _LONG_TILES:
+        raise ValueError(f"long_tiles must be one of {_LONG_TILES}")
+    if name == "segment_length" and (int(value) < 0 or (int(value) != 0 and (int(value) < 64 or int(value) % 64))):
+        raise ValueError("segment_length must be 0 (library default, 1024) or a multiple of 64")
 
 
 def set_option(name, value):
-    """weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
+    """Process default of one knob; returns the previous value.  (Per call: `options=` of GaussianRasterizer / render /
+    count_render; per thread: `with rasterizer.options(...)`.)
+    weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
     fast_exp (default True): hardware exp/rcp in render() -- training renders; set False for the canonical,
               bit-pinned arithmetic.  count renders (f_count=True) ALWAYS use the canonical arithmetic;
     profile: record per-kernel hipEvent timings (read with _lib.profile_read());
@@ -61,15 +77,59 @@ def set_option(name, value):
               True = nothing is read back at all, so one host thread can keep several views in flight on several streams.  The binning buffer is sized capacity_margin x the
               largest instance count seen so far for this (N, W, H) (the first view of a shape takes the exact path to learn it)
               and depths are laid out for max_depth (the camera's zfar; scene/cameras.py:64 uses 100).  A view that does not fit
-              is abandoned on the device; pending_overflow() (one sync for a whole batch of views) reports it and raises the
-              capacity, and the caller re-renders -- parallel.backward_over_views and the sharded prune pass do."""
-    if name == "segment_length":   # entries per backward segment of a long tile list (library-wide, default 1024; tests use 64)
-        return _lib.load().lg_set_segment_length(int(value))
-    if name == "long_tiles":       # "serial" | "auto" (default) | "parallel": lg_set_long_tile_mode (DESIGN 18)
-        return ("serial", "auto", "parallel")[_lib.load().lg_set_long_tile_mode({"serial": 0, "auto": 1, "parallel": 2}[value])]
+              is abandoned on the device; PendingBatch.resolve() / pending_status() (one sync for a whole batch of views)
+              reports it and raises the capacity, and the caller re-renders -- parallel.backward_over_views and the sharded
+              prune pass do;
+    segment_length: entries per backward segment of a long tile list (0 = the library default 1024; tests use 64 / 128);
+              travels in lg_view.segment_length, the backward of a view uses the value its forward ran with;
+    long_tiles: "serial" | "auto" (default) | "parallel": walk of outlier tile lists in training forwards; "auto" is
+              decided on the device from the view's own list statistics -- no dependence on earlier views."""
     if name not in _OPTIONS:
         raise KeyError(name)
+    _validate(name, value)
+    prev = _OPTIONS[name]
     _OPTIONS[name] = value
+    return prev
+
+
+class options:
+    """Thread-local option overrides for everything rendered inside the `with` block on THIS host thread:
+
+        with rasterizer.options(sync_free=True, skip_color_in_count=True):
+            count_render(cam, gaussians, pipe, bg)
+
+    Other threads keep their own view of the options; blocks nest (inner wins).  Besides the knobs of set_option: `pending`
+    (a PendingBatch that collects the status words of sync-free forwards instead of the process-wide list), `tag` (recorded
+    with each of them) and `status_override` (a [4] int32 tensor the next sync-free forward writes its status words to)."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if k not in _OPTIONS and k not in _PER_CALL_ONLY:
+                raise KeyError(k)
+            _validate(k, v)
+        self.kw = kw
+
+    def __enter__(self):
+        _tls.stack = getattr(_tls, "stack", ()) + (self.kw,)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack = _tls.stack[:-1]
+        return False
+
+
+def resolve_options(overrides=None):
+    """Snapshot of the options one forward runs with: process defaults < this thread's `with options(...)` blocks < overrides."""
+    o = dict(_OPTIONS)
+    for kw in getattr(_tls, "stack", ()):
+        o.update(kw)
+    if overrides:
+        for k, v in overrides.items():
+            if k not in _OPTIONS and k not in _PER_CALL_ONLY:
+                raise KeyError(k)
+            _validate(k, v)
+        o.update(overrides)
+    return o
 
 
 _GRAD_CHUNKS = {"hook": None, "chunks": 1}
@@ -85,12 +145,27 @@ def set_grad_chunk_hook(hook, chunks=4):
 
 
 def _call_backward(lib, args, grads_by_name):
-    """lg_backward, or lg_backward_chunked when a gradient-chunk hook is installed."""
+    """lg_backward, or lg_backward_chunked when a gradient-chunk hook is installed.  An exception raised by the hook cannot
+    cross the C frame (ctypes would print and swallow it, and the remaining ranges would still be reported): it is recorded,
+    the hook is not called again for this backward, and it is re-raised here once the library call has returned."""
     hook = _GRAD_CHUNKS["hook"]
     if hook is None:
         return lib.lg_backward(*args)
-    cb = _lib.CHUNK_FN(lambda _user, first, count: hook(int(first), int(count), grads_by_name))
-    return lib.lg_backward_chunked(*args, int(_GRAD_CHUNKS["chunks"]), cb, None)
+    errors = []
+
+    def _cb(_user, first, count):
+        if errors:
+            return
+        try:
+            hook(int(first), int(count), grads_by_name)
+        except BaseException as e:  # noqa: BLE001 -- re-raised below, on the Python side of the call
+            errors.append(e)
+
+    cb = _lib.CHUNK_FN(_cb)
+    rc = lib.lg_backward_chunked(*args, int(_GRAD_CHUNKS["chunks"]), cb, None)
+    if errors:
+        raise errors[0]
+    return rc
 
 
 def _ptr(t):
@@ -109,7 +184,9 @@ def _prep(t, dev):
 class _Call:
     """Holds the tensors referenced by the C structs alive for the duration of a call."""
 
-    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact, sh_rest=None, raw=False):
+    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact, sh_rest=None, raw=False, opts=None):
+        opts = opts if opts is not None else resolve_options()
+        self.opts = opts
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("lightgaussian_amd rasterizer needs tensors on a HIP device (torch 'cuda'); there is no CPU path")
@@ -131,12 +208,13 @@ class _Call:
         flags = _lib.FLAG_RAW_PARAMS if raw else 0
         if rs.debug:
             flags |= _lib.FLAG_DEBUG
-        if _OPTIONS["fast_exp"] and not exact:
+        if opts["fast_exp"] and not exact:
             flags |= _lib.FLAG_FAST_EXP
-        if _OPTIONS["profile"]:
+        if opts["profile"]:
             flags |= _lib.FLAG_PROFILE
-        if exact and _OPTIONS["skip_color_in_count"]:
+        if exact and opts["skip_color_in_count"]:
             flags |= _lib.FLAG_SKIP_COLOR
+        flags |= {"serial": _lib.FLAG_LONG_SERIAL, "auto": 0, "parallel": _lib.FLAG_LONG_PARALLEL}[opts["long_tiles"]]
         # cross-check switches (tests toggle these environment variables at run time)
         env = os.environ
         if "LG_FORCE_PAIR_SORT" in env:
@@ -147,7 +225,7 @@ class _Call:
             flags |= _lib.FLAG_K1_LDS
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
-                                 int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags)
+                                 int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags, int(opts["segment_length"]))
         self.g = _lib.lg_gaussians(N, M, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
                                    _ptr(self.scales), _ptr(self.rots), _ptr(self.cov), _ptr(self.sh_rest))
         self.N, self.M = N, M
@@ -156,38 +234,62 @@ class _Call:
 # ---- sync-free forwards: capacity bookkeeping --------------------------------------------------------------------------
 _CAP_LOCK = threading.Lock()
 _CAPACITY = {}      # (device index, N, W, H) -> binning capacity in instances
-_PENDING = []       # (status tensor [4] int32, key) of bounded forwards not yet checked
-_STATUS_OVERRIDE = None   # a [4] int32 tensor (device or pinned host) the next sync-free forwards write their status words to
+
+
+class PendingBatch:
+    """Status words of sync-free forwards (option sync_free=True) that have not been looked at yet.  A caller that keeps several
+    views in flight passes its own batch (`options(pending=batch, tag=k)`) and resolves it once: nothing another caller or
+    thread renders meanwhile can get mixed into it.  Forwards issued without one land in the process-wide batch behind
+    pending_status()."""
+
+    def __init__(self):
+        self.items = []         # (status tensor [4] int32 or None, capacity key, tag)
+        self.lock = threading.Lock()
+
+    def add(self, status, key, tag):
+        with self.lock:
+            self.items.append((status, key, tag))
+
+    def __len__(self):
+        return len(self.items)
+
+    def resolve(self):
+        """[(tag, abandoned)] in issue order: abandoned = the view did not fit its binning capacity, or held a depth beyond
+        max_depth, and must be re-rendered (its image is the background, its counts / scores / gradients are zero).  ONE host
+        sync for the whole batch; the streams that issued the views must have been joined into the current stream.
+        Capacities are raised from the instance counts the device reported, so the re-render (and later views of that
+        shape) fit."""
+        with self.lock:
+            pend, self.items = self.items, []
+        if not pend:
+            return []
+        live = [p[0] for p in pend if p[0] is not None]
+        it = iter(torch.stack([t.to(live[0].device) for t in live]).cpu().tolist() if live else [])
+        out = []
+        for st, key, tag in pend:
+            if st is None:                              # this forward took the exact path (first view of its shape)
+                out.append((tag, False))
+                continue
+            flags, _viol, _dmax, R = next(it)
+            flags &= 0xFFFFFFFF
+            R &= 0xFFFFFFFF
+            out.append((tag, flags != 0))
+            with _CAP_LOCK:
+                if flags & 2:
+                    _CAPACITY[key] = -1                # depth bound violated: this shape goes back to the exact path
+                elif (flags or key in _CAPACITY) and _CAPACITY.get(key, 0) >= 0:
+                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * _OPTIONS["capacity_margin"]) + 4096)
+        return out
+
+
+_PENDING = PendingBatch()    # forwards issued without a batch of their own
+_PENDING_CAP = 4096          # a caller that never polls must not accumulate device tensors without bound
 
 
 def pending_status():
-    """Outcome of every sync-free forward issued since the last call, in issue order: a list of booleans, True = the view
-    was abandoned on the device (more instances than its binning capacity, or a depth beyond max_depth) and must be
-    re-rendered -- its image is the background, its counts / scores / gradients are zero.  ONE host sync for the whole batch.
-    The streams that issued the views must have been joined into the current stream.  Capacities are raised from the
-    instance counts the device reported, so the re-render (and later views of that shape) fit."""
-    with _CAP_LOCK:
-        pend = list(_PENDING)
-        _PENDING.clear()
-    if not pend:
-        return []
-    live = [p[0] for p in pend if p[0] is not None]
-    it = iter(torch.stack(live).cpu().tolist() if live else [])
-    out = []
-    for st, key in pend:
-        if st is None:                              # this forward took the exact path (first view of its shape)
-            out.append(False)
-            continue
-        flags, _viol, _dmax, R = next(it)
-        flags &= 0xFFFFFFFF
-        R &= 0xFFFFFFFF
-        out.append(flags != 0)
-        with _CAP_LOCK:
-            if flags & 2:
-                _CAPACITY[key] = -1                # depth bound violated: this shape goes back to the exact path
-            elif (flags or key in _CAPACITY) and _CAPACITY.get(key, 0) >= 0:
-                _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * _OPTIONS["capacity_margin"]) + 4096)
-    return out
+    """Outcome of every sync-free forward issued WITHOUT a PendingBatch of its own since the last call, in issue order: a list
+    of booleans, True = abandoned on the device (see PendingBatch.resolve)."""
+    return [bad for _tag, bad in _PENDING.resolve()]
 
 
 def pending_overflow():
@@ -195,15 +297,25 @@ def pending_overflow():
     return any(pending_status())
 
 
-def _note_count(key, R):
+def _note_pending(opts, status, key):
+    batch = opts.get("pending")
+    if batch is None:
+        batch = _PENDING
+        if len(batch) >= _PENDING_CAP:
+            batch.resolve()                             # nobody polls: learn the capacities, drop the tensors
+    batch.add(status, key, opts.get("tag"))
+
+
+def _note_count(key, R, opts=None):
     with _CAP_LOCK:
-        want = int(R * _OPTIONS["capacity_margin"]) + 4096
+        want = int(R * (opts or _OPTIONS)["capacity_margin"]) + 4096
         have = _CAPACITY.get(key, 0)
         if have >= 0 and want > have:
             _CAPACITY[key] = want
 
 
 def _native_forward(lib, call, rs, count):
+    opts = call.opts
     """One forward through the C ABI.  Exact path (lg_forward / lg_forward_count: one blocking read of the instance count,
     as the reference extension) or, with option sync_free and a known capacity for this shape, lg_forward_bounded.
     Returns (color, radii, gcount, score, geom, binning, img, num_rendered)."""
@@ -218,41 +330,43 @@ def _native_forward(lib, call, rs, count):
     gcount = torch.empty((N,), dtype=torch.int32, device=dev) if count else None
     score = torch.empty((N,), dtype=torch.float32, device=dev) if count else None
     key = (dev.index, N, W, H)
-    mode = _OPTIONS["sync_free"]
+    mode = opts["sync_free"]
+    S = int(opts["segment_length"])
     cap = _CAPACITY.get(key) if (mode and N > 0 and not rs.prefiltered) else None
     if call.view.flags & _lib.FLAG_PAIR_SORT:
         cap = None                                 # the pair key format (cross-check switch / fields beyond 64 bits) has no bounded form
     if cap is not None and cap > 0:          # (-1: a depth beyond max_depth was seen for this shape -> exact path for good)
-        binning = torch.empty(lib.lg_binning_bytes(cap, W, H), **u8)
+        binning = torch.empty(lib.lg_binning_bytes(cap, W, H, S), **u8)
         if mode == "validated":
             # everything of the view is enqueued, then the host waits for the four status words that left right behind K2:
             # it knows R and the abort flags before returning (safe drop-in), the device never idled
             host = (C.c_uint32 * 4)()
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                        float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
+                                        float(opts["max_depth"]), int(opts["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), None, C.byref(host), stream)
             if rc == _lib.LG_ERR_INVALID_ARGUMENT and b"64 key bits" in lib.lg_last_error():
                 host[0] = 2                        # tile | depth | id do not fit one key for this shape: exact path, for good
             else:
                 _lib.check(rc)
             if host[0] == 0:
-                _note_count(key, int(host[3]))
+                _note_count(key, int(host[3]), opts)
                 return color, radii, gcount, score, geom, binning, img, cap
             with _CAP_LOCK:                        # the view did not fit (its kernels were no-ops): exact path below, same buffers
                 if host[0] & 2:
                     _CAPACITY[key] = -1
                 else:
-                    _CAPACITY[key] = int(int(host[3]) * _OPTIONS["capacity_margin"]) + 4096
+                    _CAPACITY[key] = int(int(host[3]) * opts["capacity_margin"]) + 4096
             del binning
         else:
             # (graph.GraphedStep hands in pinned host words that it polls: the kernels write them directly)
-            status = _STATUS_OVERRIDE if _STATUS_OVERRIDE is not None else torch.empty(4, dtype=torch.int32, device=dev)
+            status = opts.get("status_override")
+            if status is None:
+                status = torch.empty(4, dtype=torch.int32, device=dev)
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                        float(_OPTIONS["max_depth"]), int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii),
+                                        float(opts["max_depth"]), int(opts["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), _ptr(status), None, stream)
             _lib.check(rc)
-            with _CAP_LOCK:
-                _PENDING.append((status, key))
+            _note_pending(opts, status, key)
             return color, radii, gcount, score, geom, binning, img, cap
     holder = {}
 
@@ -265,17 +379,16 @@ def _native_forward(lib, call, rs, count):
     R = C.c_int64(0)
     if count:
         rc = lib.lg_forward_count(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None,
-                                  int(_OPTIONS["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount), _ptr(score),
+                                  int(opts["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount), _ptr(score),
                                   C.byref(bin_ptr), C.byref(R), stream)
     else:
         rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),
                             C.byref(bin_ptr), C.byref(R), stream)
     _lib.check(rc)
     if mode:
-        _note_count(key, int(R.value))
+        _note_count(key, int(R.value), opts)
         if mode != "validated":
-            with _CAP_LOCK:
-                _PENDING.append((None, key))       # keeps pending_status() aligned with the issue order
+            _note_pending(opts, None, key)         # keeps the batch aligned with the issue order
     return color, radii, gcount, score, geom, holder.get("t"), img, int(R.value)
 
 
@@ -290,15 +403,17 @@ def _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, options=None):
         lib = _lib.load()
         rs = raster_settings
         count = bool(rs.f_count)
-        call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count)
+        opts = resolve_options(options)
+        call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count, opts=opts)
         with torch.cuda.device(call.dev):
             color, radii, gcount, score, geom, binning, img, num_rendered = _native_forward(lib, call, rs, count)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.opts = {k: v for k, v in opts.items() if k not in _PER_CALL_ONLY}   # the backward runs with the forward's options
         ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
                    scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
         ctx.save_for_backward(call.means3D, call.sh, call.colors, call.opac, call.scales, call.rots, call.cov, radii,
@@ -315,7 +430,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         grad_color = grads[2] if rs.f_count else grads[0]
         means3D, sh, colors, opac, scales, rots, cov, radii, geom, binning, img = ctx.saved_tensors
-        call = _Call(rs, means3D, sh, colors, opac, scales, rots, cov, exact=bool(rs.f_count))
+        call = _Call(rs, means3D, sh, colors, opac, scales, rots, cov, exact=bool(rs.f_count), opts=ctx.opts)
         dev, N, M = call.dev, call.N, call.M
         H, W = int(rs.image_height), int(rs.image_width)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -342,7 +457,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(rc)
         had_sh, had_col, had_sc, had_cov = ctx.had
         return (g_means3D, g_means2D, g_sh if had_sh else None, g_col if had_col else None, g_opac,
-                g_sc if had_sc else None, g_rot if had_sc else None, g_cov if had_cov else None, None)
+                g_sc if had_sc else None, g_rot if had_sc else None, g_cov if had_cov else None, None, None)
 
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):
@@ -351,17 +466,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     _features_dc/_features_rest run inside K1, their backward inside K9 (LG_FLAG_RAW_PARAMS)."""
 
     @staticmethod
-    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings):
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings, options=None):
         lib = _lib.load()
         rs = raster_settings
+        opts = resolve_options(options)
         if rs.f_count:
             raise Exception("raw-parameter rasterisation is a training path; use count_render for significance")
         rest = features_rest if (features_rest is not None and features_rest.shape[1] > 0) else None
-        call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True)
+        call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True, opts=opts)
         with torch.cuda.device(call.dev):
             color, radii, _gc, _sc, geom, binning, img, num_rendered = _native_forward(lib, call, rs, False)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.opts = {k: v for k, v in opts.items() if k not in _PER_CALL_ONLY}
         ctx.has_rest = rest is not None
         ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
         ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, binning, img)
@@ -373,7 +490,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         lib = _lib.load()
         rs = ctx.raster_settings
         xyz, dc, rest, opac, scales, rots, radii, geom, binning, img = ctx.saved_tensors
-        call = _Call(rs, xyz, dc, None, opac, scales, rots, None, exact=False, sh_rest=rest, raw=True)
+        call = _Call(rs, xyz, dc, None, opac, scales, rots, None, exact=False, sh_rest=rest, raw=True, opts=ctx.opts)
         dev, N = call.dev, call.N
         H, W = int(rs.image_height), int(rs.image_width)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -393,26 +510,30 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             _lib.check(rc)
         if g_rest is None and ctx.rest_shape is not None:
             g_rest = torch.zeros(ctx.rest_shape, **f32)
-        return g_xyz, g_means2D, g_dc, g_rest, g_opac, g_sc, g_rot, None
+        return g_xyz, g_means2D, g_dc, g_rest, g_opac, g_sc, g_rot, None, None
 
 
-def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings):
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings,
+                            options=None):
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations,
-                                        raster_settings)
+                                        raster_settings, options)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, options=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, options)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings, f_count=None):
+    def __init__(self, raster_settings, f_count=None, options=None):
+        """raster_settings: the reference's 13-field record.  options (extension, not in the reference): a dict of per-call
+        overrides of the knobs documented at set_option -- e.g. {"skip_color_in_count": True, "sync_free": True}."""
         super().__init__()
         if f_count is not None:  # stale ctor form, gaussian_renderer/gaussian_count.py:69
             raster_settings = raster_settings._replace(f_count=bool(f_count))
         self.raster_settings = raster_settings
+        self.options = dict(options) if options else None
 
     def markVisible(self, positions):
         """Frustum test only (never called by the reference; kept for API completeness)."""
@@ -425,11 +546,11 @@ class GaussianRasterizer(nn.Module):
                 cov3D_precomp=None):
         _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings)
+                                   self.raster_settings, self.options)
 
     def forward_counter(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                         cov3D_precomp=None):
         """Stale count entry point (gaussian_renderer/gaussian_count.py:112)."""
         _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
         rs = self.raster_settings._replace(f_count=True)
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, self.options)

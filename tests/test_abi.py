@@ -34,7 +34,7 @@ def test_library_built_loads_and_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/lightgaussian.h but not exported"
     lib.lg_abi_version.restype = C.c_int
-    assert lib.lg_abi_version() == 4
+    assert lib.lg_abi_version() == 5
     lib.lg_img_bytes.restype = C.c_size_t
     lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     assert lib.lg_img_bytes(1920, 1080) >= 1920 * 1080 * 8
@@ -82,22 +82,70 @@ def test_product_never_imports_the_oracle():
         assert "lg_oracle" not in open(path).read(), path
 
 
-def test_process_wide_setters_return_the_previous_value_and_reject_nonsense():
-    """lg_set_segment_length / lg_set_long_tile_mode (no device needed: host state only)."""
+def test_the_library_has_no_process_wide_setters_and_the_segment_length_travels_with_the_view():
+    """ABI v5 (r2 verdict): lg_set_segment_length / lg_set_long_tile_mode are gone -- the segment length is a field of lg_view,
+    the long-tile mode two flag bits -- and the buffer size is a pure function of its arguments (no device needed here)."""
     lib = _lib.load()
-    prev = lib.lg_set_segment_length(128)
-    try:
-        assert lib.lg_set_segment_length(100) == 128          # not a multiple of 64: ignored ...
-        assert lib.lg_set_segment_length(32) == 128           # ... as is anything below 64
-        assert lib.lg_set_segment_length(256) == 128
-        assert lib.lg_binning_bytes(100000, 640, 480) > 0
-    finally:
-        lib.lg_set_segment_length(prev)
-    mode = lib.lg_set_long_tile_mode(0)                       # 0 serial, 1 auto (default), 2 parallel
-    try:
-        assert mode in (0, 1, 2)
-        assert lib.lg_set_long_tile_mode(2) == 0
-        assert lib.lg_set_long_tile_mode(7) == 2 and lib.lg_set_long_tile_mode(-1) == 2   # out of range: unchanged
-        assert lib.lg_set_long_tile_mode(0) == 2
-    finally:
-        lib.lg_set_long_tile_mode(0 if mode == 1 else mode)  # (mode 1 touches pinned host memory: not from a test without a device)
+    assert not hasattr(lib, "lg_set_segment_length") and not hasattr(lib, "lg_set_long_tile_mode")
+    for name in ("lg_set_segment_length", "lg_set_long_tile_mode"):
+        with pytest.raises(AttributeError):
+            getattr(C.CDLL(_lib.LIB_PATH), name)
+    assert [f[0] for f in _lib.lg_view._fields_][-1] == "segment_length"
+    a, b = lib.lg_binning_bytes(100000, 640, 480, 0), lib.lg_binning_bytes(100000, 640, 480, 1024)
+    assert a == b > 0                                                   # 0 = the default of 1024
+    assert lib.lg_binning_bytes(100000, 640, 480, 64) > a               # more checkpoint records for shorter segments
+    assert lib.lg_binning_bytes(100000, 640, 480, 100) == 0             # not a multiple of 64
+    assert lib.lg_binning_bytes(100000, 640, 480, 32) == 0              # below 64
+    assert lib.lg_binning_bytes(100000, 640, 480, 0) == a               # ... and asking twice changes nothing
+    # a view with a bad segment length or contradictory long-tile flags is refused before any launch
+    v = _lib.lg_view(8, 8, 1.0, 1.0, None, 1.0, None, None, 0, None, 0, 0, 100)
+    g = _lib.lg_gaussians(0, 0, None, None, None, None, None, None, None, None)
+    cb = _lib.ALLOC_FN(lambda u, n: 0)
+    assert lib.lg_forward(C.byref(v), C.byref(g), None, None, cb, None, None, None, None, None, None) == _lib.LG_ERR_INVALID_ARGUMENT
+    assert b"segment_length" in lib.lg_last_error()
+    v = _lib.lg_view(8, 8, 1.0, 1.0, None, 1.0, None, None, 0, None, 0, _lib.FLAG_LONG_SERIAL | _lib.FLAG_LONG_PARALLEL, 0)
+    assert lib.lg_forward(C.byref(v), C.byref(g), None, None, cb, None, None, None, None, None, None) == _lib.LG_ERR_INVALID_ARGUMENT
+    assert b"exclude each other" in lib.lg_last_error()
+
+
+def test_options_are_resolved_per_call_and_per_thread_never_by_mutating_the_defaults():
+    """rasterizer.options(...) is thread-local and nests; an `options=` argument wins; the process defaults stay untouched
+    (r2 verdict: prune_list_sharded / _ViewRunner used to flip module-level switches under other threads' feet)."""
+    import threading
+    from lightgaussian_amd import rasterizer as R
+    base = dict(R._OPTIONS)
+    seen = {}
+
+    def other():
+        seen["other"] = R.resolve_options()
+
+    with R.options(sync_free=True, skip_color_in_count=True):
+        with R.options(tag=7, long_tiles="serial"):
+            inner = R.resolve_options({"segment_length": 128})
+            t = threading.Thread(target=other); t.start(); t.join()
+        mid = R.resolve_options()
+    assert inner["sync_free"] is True and inner["skip_color_in_count"] is True and inner["tag"] == 7
+    assert inner["long_tiles"] == "serial" and inner["segment_length"] == 128
+    assert mid["long_tiles"] == base["long_tiles"] and "tag" not in mid and mid["sync_free"] is True
+    assert seen["other"] == base                                          # the other thread saw the defaults
+    assert R.resolve_options() == base and R._OPTIONS == base
+    with pytest.raises(KeyError):
+        R.options(no_such_knob=1)
+    with pytest.raises(ValueError):
+        R.resolve_options({"segment_length": 100})
+    with pytest.raises(ValueError):
+        R.set_option("long_tiles", "sometimes")
+    assert R.set_option("long_tiles", "parallel") == base["long_tiles"]   # returns the previous default
+    assert R.set_option("long_tiles", base["long_tiles"]) == "parallel"
+    # a PendingBatch keeps the status words of ITS forwards only, tagged
+    b = R.PendingBatch()
+    b.add(None, ("k",), 3); b.add(None, ("k",), 5)
+    assert b.resolve() == [(3, False), (5, False)] and b.resolve() == []
+
+
+def test_prune_pass_and_view_runner_do_not_touch_the_process_defaults():
+    import inspect
+    from lightgaussian_amd import prune, parallel, graph
+    for mod in (prune, parallel, graph):
+        src = inspect.getsource(mod)
+        assert "set_option(" not in src and "_OPTIONS[" not in src, mod.__name__

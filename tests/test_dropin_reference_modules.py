@@ -54,7 +54,8 @@ class _Recorder:
         from lightgaussian_amd import rasterizer
         self.calls = []
 
-        def fake(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        def fake(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, options=None):
+            assert options is None        # the reference never passes per-call options (an extension of this repo)
             self.calls.append(dict(means3D=means3D, means2D=means2D, shs=sh, colors_precomp=colors_precomp, opacities=opacities,
                                    scales=scales, rotations=rotations, cov3D_precomp=cov3Ds_precomp, settings=raster_settings))
             n = means3D.shape[0]

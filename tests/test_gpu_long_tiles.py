@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    rasterizer.set_option("segment_length", 1024)
-    rasterizer.set_option("long_tiles", "serial")
+    rasterizer.set_option("segment_length", 0)
+    rasterizer.set_option("long_tiles", "auto")
 
 
 def _np(kw):
@@ -158,29 +158,69 @@ def test_parallel_long_tile_forward_leaves_n_contrib_and_final_T_of_the_serial_w
     assert float((outs["serial"][0] - outs["parallel"][0]).abs().max()) <= 3e-6
 
 
-def test_long_tile_mode_auto_switches_after_the_first_long_view():
-    """ "auto" (the library default): a list goes through the parallel kernels when it is longer than two segments and four times
-    the view's mean list, and only once a view of the process has reported such a list (pinned hint word) -- the first such view
-    is still walked serially.  Ordinary multi-segment lists stay with the serial walk (sending every 2-3-segment tile of a dense
-    scene through the parallel kernels was slower), so a scene without an outlier never switches."""
+def test_long_tile_mode_auto_is_a_pure_function_of_the_view():
+    """ "auto" (the default): a list goes through the parallel kernels when it is longer than two segments and four times the
+    view's mean list -- decided on the device from THIS view's instance count (lg_par_min).  No history: the first render of an
+    outlier scene already takes the parallel walk, renders of other scenes in between change nothing, and two renders of the same
+    inputs are bit-identical.  Ordinary multi-segment lists stay with the serial walk, so a scene without an outlier renders
+    exactly as under "serial"."""
     # 27 000 tiny splats spread over 300 tiles (mean list ~ 100) + a pile of 3 000 larger faint ones on a handful of tiles
     g = syn.make_gaussians(30000, seed=5, log_scale_mean=math.log(0.01), opacity_mean=-1.0, extent=(2, 1.2, 2))
     syn.make_heavy_tailed(g, frac=0.1, radius=0.1, log_scale_mean=math.log(0.06), opacity_mean=-3.5)
     kw = common.scene_kwargs(g, syn.orbit_camera(1, 7, 320, 240, radius=5.0), 320, 240, deg=3, bg=(0.2, 0.1, 0.3), as_torch=True)
-    rasterizer.set_option("segment_length", 64)
-    rasterizer.set_option("long_tiles", "serial")
-    serial = gpu_common.hip_forward_backward(kw)["color"]
-    rasterizer.set_option("long_tiles", "auto")                    # starts from a clean hint
-    first = gpu_common.hip_forward_backward(kw)["color"]
-    torch.cuda.synchronize()
-    second = gpu_common.hip_forward_backward(kw)["color"]
-    assert np.array_equal(first, serial)                           # nothing known yet: serial walk; its work-list workgroup raises the hint
-    assert not np.array_equal(second, serial) and np.abs(second - serial).max() <= 3e-6
-    # a scene without an outlier list never raises the hint ("auto" starts clean again)
     small = _scene(**SCENES[0])
+    gimg = np.random.RandomState(5).randn(3, 240, 320).astype(np.float32)
+    rasterizer.set_option("segment_length", 64)
+    rasterizer.set_option("long_tiles", "auto")
+    first = gpu_common.hip_forward_backward(kw, grad_image=gimg)                     # nothing rendered before in this mode
+    gpu_common.hip_forward_backward(small)                                           # another scene in between
+    second = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    rasterizer.set_option("long_tiles", "serial")
+    serial = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    assert np.array_equal(first["color"], second["color"])                           # history-free, run-to-run bit-identical
+    for name in first["grads"]:
+        assert np.array_equal(first["grads"][name], second["grads"][name]), name
+    assert not np.array_equal(first["color"], serial["color"])                       # the outlier lists took the parallel walk ...
+    assert np.abs(first["color"] - serial["color"]).max() <= 3e-6                    # ... same image to float rounding
+    # a scene without an outlier list: "auto" == "serial", bit for bit
+    c = gpu_common.hip_forward_backward(small)["color"]
     rasterizer.set_option("long_tiles", "auto")
     a = gpu_common.hip_forward_backward(small)["color"]
-    b = gpu_common.hip_forward_backward(small)["color"]
-    rasterizer.set_option("long_tiles", "serial")
-    c = gpu_common.hip_forward_backward(small)["color"]
-    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(a, c)
+
+
+def test_the_backward_runs_with_the_segment_length_of_its_forward():
+    """The segment length is part of the call (lg_view.segment_length), snapshotted by the forward: changing the process default
+    between a forward and its backward changes nothing (r2: a process-wide word read independently by both silently corrupted
+    the checkpoint addressing).  At the C ABI a backward handed another segment length than its forward refuses to touch the
+    buffers: zero gradients, and an error under LG_FLAG_DEBUG."""
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    g = syn.make_gaussians(6000, seed=4, log_scale_mean=math.log(0.06), opacity_mean=-3.0, extent=(2, 1.2, 2))
+    cam = syn.orbit_camera(1, 7, 160, 96, radius=5.0).to(dev)
+    pipe, bg = syn.PipelineParams(), torch.zeros(3, device=dev)
+    gimg = torch.randn(3, 96, 160, device=dev)
+    grads = []
+    for flip in (False, True):
+        pc = g.to(dev).requires_grad_(True)
+        rasterizer.set_option("segment_length", 64)
+        img = render(cam, pc, pipe, bg)["render"]
+        if flip:
+            rasterizer.set_option("segment_length", 128)          # between forward and backward
+        (img * gimg).sum().backward()
+        grads.append([p.grad.clone() for p in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b) and float(a.abs().sum()) > 0
+    # C ABI: forward at S = 64, backward deliberately at S = 128 (the options snapshot of the autograd node overwritten)
+    pc = g.to(dev).requires_grad_(True)
+    rasterizer.set_option("segment_length", 64)
+    img = render(cam, pc, pipe, bg)["render"]
+    img.grad_fn.opts = dict(img.grad_fn.opts, segment_length=128)
+    (img * gimg).sum().backward()
+    assert float(pc._xyz.grad.abs().sum()) == 0.0 and float(pc._opacity.grad.abs().sum()) == 0.0
+    pipe_dbg = syn.PipelineParams(); pipe_dbg.debug = True
+    pc = g.to(dev).requires_grad_(True)
+    img = render(cam, pc, pipe_dbg, bg)["render"]
+    img.grad_fn.opts = dict(img.grad_fn.opts, segment_length=128)
+    with pytest.raises(Exception, match="segment_length differs"):
+        (img * gimg).sum().backward()

@@ -33,7 +33,7 @@ refs = {}
 for k, o in other.items():
     setcam(o)
     out = body()
-    st = rasterizer._PENDING[-1][0].clone()
+    st = rasterizer._PENDING.items[-1][0].clone()
     refs[k] = (out["render"].clone(), out["radii"].clone(), st.tolist())
 rasterizer.pending_status()
 setcam(keep)
@@ -45,7 +45,7 @@ rasterizer.pending_status()
 graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph):
     out = body()
-status = rasterizer._PENDING[-1][0]
+status = rasterizer._PENDING.items[-1][0]
 big = torch.empty(1 << 28, dtype=torch.uint8, device=dev) if thrash else None
 for k in seq:
     setcam(other[k])
