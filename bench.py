@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--sync-free", choices=["default", "off", "validated"], default="default",
                     help="rasterizer option sync_free for the timed loop: validated = bounded forward, status words read after the whole "
                          "view is enqueued (no idle device at the read-back of R); off = the exact forward with its blocking read-back")
+    ap.add_argument("--segment-length", type=int, default=0, help="rasterizer option segment_length (0 = library default 1024): per-tile lists longer than this "
+                    "are cut into independent (tile, segment) work items of the backward")
+    ap.add_argument("--long-tiles", choices=["serial", "auto", "parallel"], default="auto", help="rasterizer option long_tiles (walk of outlier tile lists in the forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
@@ -215,6 +218,8 @@ def main():
 
     _lib.load()
     rasterizer.set_option("fast_exp", not args.exact_exp)
+    rasterizer.set_option("segment_length", args.segment_length)
+    rasterizer.set_option("long_tiles", args.long_tiles)
     if args.sync_free != "default":
         rasterizer.set_option("sync_free", False if args.sync_free == "off" else "validated")
     N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2

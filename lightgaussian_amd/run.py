@@ -1,0 +1,277 @@
+"""Drop-in runner: the reference's UNMODIFIED trainers on the MI355X path.
+
+    python -m lightgaussian_amd.run /path/to/LightGaussian/prune_finetune.py -s <scene> -m <out> --start_checkpoint ...
+    python -m lightgaussian_amd.run /path/to/LightGaussian/distill_train.py ...
+    python -m lightgaussian_amd.run /path/to/LightGaussian/train_densify_prune.py ...
+    python -m torch.distributed.run --nproc-per-node 8 -m lightgaussian_amd.run --distributed /path/to/prune_finetune.py ...
+
+Why a runner.  The trainers import their collaborators by name from their own directory, which Python puts first on sys.path:
+    from utils.loss_utils import l1_loss, ssim                 prune_finetune.py:15, distill_train.py:15, train_densify_prune.py
+    from gaussian_renderer import render, count_render         prune_finetune.py:17, distill_train.py:16, train_densify_prune.py:11
+    from prune import prune_list, calculate_v_imp_score        prune_finetune.py:39
+    from scene import Scene, GaussianModel                     prune_finetune.py:19
+With only PYTHONPATH=<this repo> the `diff_gaussian_rasterization` / `simple_knn` shims resolve, i.e. the rasterizer and the
+kNN are replaced, but everything around them is still the reference's torch code: render() evaluates the getters in torch on
+every call (the literal pattern: 338 views/s instead of 551 at 3 M Gaussians / 1080p), SSIM is five grouped conv2d (10.8 ms per
+step at 1080p, three times the whole render), prune_list walks the views one by one, prune_points runs 21 boolean-index kernels,
+the VecTree search materialises cdist.  patch_reference() imports the reference's modules and REBINDS those symbols -- in
+the modules themselves and in every module that already imported them by name -- to the implementations of this package:
+
+    reference symbol                                   rebound to
+    gaussian_renderer.render / count_render            lightgaussian_amd.gaussian_renderer.render / count_render  (getters fused into K1/K9)
+    utils.loss_utils.l1_loss / ssim                    lightgaussian_amd.loss_utils.l1_loss / ssim                (one fused L1 + SSIM launch pair)
+    prune.prune_list                                   lightgaussian_amd.prune.prune_list_sharded                 (views in flight; RCCL when a group exists)
+    prune.calculate_v_imp_score                        prune_epilogue's v_list (radix select instead of a full sort; bit-identical)
+    scene.gaussian_model.GaussianModel.prune_points    lightgaussian_amd.prune.prune_points                       (one compaction launch)
+    scene.gaussian_model.GaussianModel.prune_gaussians lightgaussian_amd.prune.prune_gaussians                    (radix select + the above)
+    vectree.vq: -torch.cdist(x, c) -> argmax           lightgaussian_amd.vq.nearest_code                          (both sites: EuclideanCodebook.forward
+                                                                                                                   :262-266 and kmeans() :131-137)
+Same signatures, same return values (tests/test_dropin_runner.py asserts the call contracts on the reference's own modules;
+tests/test_gpu_dropin_runner.py runs the body of prune_finetune.py:150-170 through the patched names against the unpatched
+literal path).  unpatch_reference() restores everything.  There is no CPU fallback behind any of these: CPU tensors raise.
+"""
+import importlib
+import os
+import runpy
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PATCHED = []          # (owner object, attribute name, original value) in patch order
+_REPORT = {}
+
+
+def _rebind_everywhere(old, new):
+    """`from module import name` copies the binding: every module that already holds the original under any name gets the
+    replacement too (the trainers' own globals included, when patching happens after their imports)."""
+    n = 0
+    for mod in list(sys.modules.values()):
+        d = getattr(mod, "__dict__", None)
+        if not isinstance(d, dict) or getattr(mod, "__name__", "").startswith("lightgaussian_amd"):
+            continue
+        for k, v in list(d.items()):
+            if v is old and v is not new:
+                _PATCHED.append((mod, k, old))
+                setattr(mod, k, new)
+                n += 1
+    return n
+
+
+def _set(owner, name, new, label):
+    old = getattr(owner, name)
+    if old is new:
+        return
+    _PATCHED.append((owner, name, old))
+    setattr(owner, name, new)
+    _REPORT[label] = {"old": f"{getattr(old, '__module__', '?')}.{getattr(old, '__qualname__', name)}",
+                      "new": f"{getattr(new, '__module__', '?')}.{getattr(new, '__qualname__', name)}"}
+    if callable(old) and not isinstance(owner, type):
+        _REPORT[label]["also_rebound_in"] = _rebind_everywhere(old, new)
+
+
+def _module(name):
+    try:
+        return sys.modules.get(name) or importlib.import_module(name)
+    except Exception as e:  # noqa: BLE001 -- a missing optional collaborator (vectree needs einops, scene needs plyfile ...) is reported
+        _REPORT[name] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+        return None
+
+
+# ---- replacements that need an adapter (same signature as the reference symbol they stand in for) -------------------------------
+
+def _prune_list(gaussians, scene, pipe, background):
+    """prune.py:133-157 prune_list(gaussians, scene, pipe, background) -> (gaussian_list, imp_list)."""
+    import torch
+    from . import prune as lg_prune
+    with torch.no_grad():       # (the reference's first view is not detached, prune.py:137-141; nothing downstream differentiates it)
+        return lg_prune.prune_list_sharded(gaussians, scene, pipe, background)
+
+
+def _calculate_v_imp_score(gaussians, imp_list, v_pow):
+    """prune.py:112-128; the kth volume by one radix select instead of a full descending sort -- same element, same v_list."""
+    import torch
+    from . import prune as lg_prune
+    if not (torch.is_tensor(imp_list) and imp_list.is_cuda and imp_list.dtype == torch.float32 and imp_list.numel() > 0):
+        return lg_prune.calculate_v_imp_score(gaussians, imp_list, v_pow)
+    volume = torch.prod(gaussians.get_scaling, dim=1)                                  # prune.py:120
+    n = volume.shape[0]
+    with torch.no_grad():                                                              # prune.py:122-124: element int(0.9 N) of the descending sort
+        kth, _ = lg_prune._select_mask(volume.detach().contiguous().float(), n - 1 - min(int(n * 0.9), n - 1), want_mask=False)
+    v_list = torch.pow(volume / kth[0], v_pow)                                         # prune.py:126-127, the reference's own ops
+    return v_list * imp_list
+
+
+def _prune_points(self, mask):
+    """GaussianModel.prune_points(mask), scene/gaussian_model.py:584-600."""
+    from . import prune as lg_prune
+    lg_prune.prune_points(self, mask)
+
+
+def _prune_gaussians(self, percent, import_score):
+    """GaussianModel.prune_gaussians(percent, import_score), scene/gaussian_model.py:776-782.  Float scores: threshold by one
+    radix select.  Integer scores (prune_type "count" hands over the int32 hit counts, prune_finetune.py:229-232): the
+    reference's own sort formulation (a float conversion could merge neighbouring counts), then the compaction."""
+    import torch
+    from . import prune as lg_prune
+    if torch.is_tensor(import_score) and import_score.is_cuda and import_score.dtype == torch.float32:
+        lg_prune.prune_gaussians(self, percent, import_score)
+    else:
+        lg_prune.prune_points(self, lg_prune.prune_mask(percent, import_score))
+
+
+class _LazyNegDist:
+    """What `-torch.cdist(x, c, p=2)` evaluates to inside the patched vectree.vq module: the two operands, nothing computed.
+    argmax over the last dimension -- the only thing the reference does with it at temperature 0 (vq.py:266 via gumbel_sample,
+    :137 torch.argmax) -- is the nearest-code search on the matrix cores; anything else materialises the real tensor."""
+
+    def __init__(self, a, b, negated=False):
+        self.a, self.b, self.negated = a, b, negated
+
+    def __neg__(self):
+        return _LazyNegDist(self.a, self.b, not self.negated)
+
+    def materialize(self):
+        import torch
+        d = torch.cdist(self.a, self.b, p=2)
+        return -d if self.negated else d
+
+    def nearest(self):
+        from . import vq as lg_vq
+        return lg_vq.nearest_code(self.a, self.b)
+
+    def __getattr__(self, name):            # any other use: behave like the tensor the reference would have had
+        return getattr(self.materialize(), name)
+
+
+def _patch_vq(vq_mod):
+    import torch
+
+    class _TorchProxy:
+        """Stands in for the name `torch` inside vectree/vq.py: cdist of two HIP float tensors (p = 2) is deferred, argmax of a
+        deferred negated distance is the fused search; every other attribute is torch's own."""
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def cdist(a, b, p=2, *args, **kw):
+            ok = (p == 2 and not args and not kw and torch.is_tensor(a) and torch.is_tensor(b) and a.is_cuda and b.is_cuda
+                  and a.dim() in (2, 3) and a.dim() == b.dim() and 1 <= a.shape[-1] <= 63 and a.dtype == torch.float32 and b.dtype == torch.float32)
+            return _LazyNegDist(a, b) if ok else torch.cdist(a, b, p, *args, **kw)
+
+        @staticmethod
+        def argmax(t, *args, **kw):
+            dim = kw.get("dim", args[0] if args else None)
+            if isinstance(t, _LazyNegDist):
+                if t.negated and dim == -1 and not kw.get("keepdim", False):
+                    return t.nearest()
+                t = t.materialize()
+            return torch.argmax(t, *args, **kw)
+
+    orig_gumbel = vq_mod.gumbel_sample
+
+    def gumbel_sample(t, temperature=1.0, dim=-1):
+        """vectree/vq.py gumbel_sample: temperature 0 is a plain argmax (the only setting the reference's VecTree uses)."""
+        if isinstance(t, _LazyNegDist):
+            if temperature == 0 and dim == -1 and t.negated:
+                return t.nearest()
+            t = t.materialize()
+        return orig_gumbel(t, temperature=temperature, dim=dim)
+
+    _set(vq_mod, "torch", _TorchProxy(), "vectree.vq.torch (cdist -> deferred, argmax -> nearest_code)")
+    _PATCHED.append((vq_mod, "gumbel_sample", orig_gumbel))
+    vq_mod.gumbel_sample = gumbel_sample
+    _REPORT["vectree.vq.gumbel_sample"] = {"old": "vectree.vq.gumbel_sample", "new": "lightgaussian_amd.run gumbel_sample -> lightgaussian_amd.vq.nearest_code"}
+
+
+def patch_reference(verbose=False):
+    """Import the reference's modules (they must be importable: run from / put on sys.path the reference checkout, with this
+    repo on the path for the `diff_gaussian_rasterization` / `simple_knn` shims) and rebind the symbols listed in the module
+    docstring.  Idempotent.  Returns a report {symbol: {"old": ..., "new": ..., "also_rebound_in": n}} (or {"skipped": why})."""
+    from . import gaussian_renderer as lg_gr
+    from . import loss_utils as lg_loss
+    gr = _module("gaussian_renderer")
+    if gr is not None:
+        _set(gr, "render", lg_gr.render, "gaussian_renderer.render")
+        _set(gr, "count_render", lg_gr.count_render, "gaussian_renderer.count_render")
+    lu = _module("utils.loss_utils")
+    if lu is not None:
+        _set(lu, "l1_loss", lg_loss.l1_loss, "utils.loss_utils.l1_loss")
+        _set(lu, "ssim", lg_loss.ssim, "utils.loss_utils.ssim")
+    pr = _module("prune")
+    if pr is not None and os.path.abspath(getattr(pr, "__file__", "")).startswith(_ROOT + os.sep + "lightgaussian_amd"):
+        pr = None                                                   # (our own module under that name: nothing to patch)
+    if pr is not None:
+        _set(pr, "prune_list", _prune_list, "prune.prune_list")
+        _set(pr, "calculate_v_imp_score", _calculate_v_imp_score, "prune.calculate_v_imp_score")
+    gm = _module("scene.gaussian_model")
+    if gm is not None and hasattr(gm, "GaussianModel"):
+        _set(gm.GaussianModel, "prune_points", _prune_points, "scene.gaussian_model.GaussianModel.prune_points")
+        _set(gm.GaussianModel, "prune_gaussians", _prune_gaussians, "scene.gaussian_model.GaussianModel.prune_gaussians")
+    vq_mod = _module("vectree.vq")
+    if vq_mod is not None and hasattr(vq_mod, "EuclideanCodebook") and not isinstance(getattr(vq_mod, "torch", None), type(None)) \
+            and type(getattr(vq_mod, "torch")).__name__ != "_TorchProxy":
+        _patch_vq(vq_mod)
+    if verbose:
+        for k, v in _REPORT.items():
+            print(f"[lightgaussian_amd.run] {k}: {v}", file=sys.stderr)
+    return dict(_REPORT)
+
+
+def unpatch_reference():
+    """Undo patch_reference() (reverse order)."""
+    while _PATCHED:
+        owner, name, old = _PATCHED.pop()
+        setattr(owner, name, old)
+    _REPORT.clear()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    distributed = no_patch = verbose = False
+    while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
+        flag = argv.pop(0)
+        if flag == "--distributed":
+            distributed = True
+        elif flag == "--no-patch":
+            no_patch = True
+        elif flag == "--verbose":
+            verbose = True
+        else:
+            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose, then the script and ITS arguments)")
+    if not argv:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(argv[0])
+    if not os.path.exists(script):
+        raise SystemExit(f"lightgaussian_amd.run: {script} does not exist")
+    # what `python script.py` sets up: the script's directory first; then this repo, so that the shims resolve
+    sys.argv = [script] + argv[1:]
+    for p in (_ROOT, os.path.dirname(script)):
+        if p in sys.path:
+            sys.path.remove(p)
+    sys.path.insert(0, _ROOT)
+    sys.path.insert(0, os.path.dirname(script))
+    if distributed:
+        # one process per GPU (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE).  The trainers' safe_state() forces
+        # "cuda:0" (utils/general_utils.py:151): this rank's GPU is made the only visible one BEFORE the HIP runtime starts, so
+        # that "cuda:0" is the right device on every rank
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+            os.environ["HIP_VISIBLE_DEVICES"] = str(local)
+            local = 0
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not no_patch:
+        report = patch_reference(verbose=verbose)
+        missing = [k for k, v in report.items() if "skipped" in v]
+        if missing and verbose:
+            print(f"[lightgaussian_amd.run] not patched (module not importable): {missing}", file=sys.stderr)
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

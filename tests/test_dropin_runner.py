@@ -1,0 +1,115 @@
+"""CPU: lightgaussian_amd.run.patch_reference() on the REFERENCE's own modules (imported unmodified over the shims, as
+tests/test_dropin_reference_modules.py does): every symbol of the runner's table is rebound, in the owning module AND in a
+module that had imported it by name beforehand (what the trainers do), signatures stay call-compatible, and
+unpatch_reference() restores the originals.  (The GPU behaviour of the rebound paths: tests/test_gpu_dropin_runner.py.)"""
+import importlib
+import inspect
+import sys
+import types
+
+import pytest
+import torch
+
+import dropin_common
+from lightgaussian_amd import run as lg_run
+
+pytestmark = pytest.mark.skipif(not dropin_common.available(), reason="/root/reference is not present on this box")
+
+
+@pytest.fixture()
+def ref():
+    mods = dropin_common.load()
+    lu = importlib.import_module("utils.loss_utils")
+    vq = importlib.import_module("vectree.vq")
+    yield mods + (lu, vq)
+    lg_run.unpatch_reference()
+
+
+def _positional(fn):
+    return [p.name for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+
+
+def test_every_symbol_of_the_table_is_rebound_and_restored(ref):
+    gr, gm, pr, lu, vq = ref
+    # a "trainer" that imported the names before the patch, the way prune_finetune.py:15-17,39 does
+    trainer = types.ModuleType("fake_trainer")
+    trainer.render, trainer.count_render = gr.render, gr.count_render
+    trainer.l1_loss, trainer.ssim = lu.l1_loss, lu.ssim
+    trainer.prune_list, trainer.calculate_v_imp_score = pr.prune_list, pr.calculate_v_imp_score
+    trainer.renamed_render = gr.render
+    sys.modules["fake_trainer"] = trainer
+    originals = {"render": gr.render, "count_render": gr.count_render, "l1_loss": lu.l1_loss, "ssim": lu.ssim, "prune_list": pr.prune_list,
+                 "calculate_v_imp_score": pr.calculate_v_imp_score, "prune_points": gm.GaussianModel.prune_points,
+                 "prune_gaussians": gm.GaussianModel.prune_gaussians, "gumbel_sample": vq.gumbel_sample, "vq_torch": vq.torch}
+    try:
+        report = lg_run.patch_reference()
+        from lightgaussian_amd import gaussian_renderer as lg_gr, loss_utils as lg_loss
+        assert gr.render is lg_gr.render and gr.count_render is lg_gr.count_render
+        assert lu.l1_loss is lg_loss.l1_loss and lu.ssim is lg_loss.ssim
+        assert pr.prune_list is lg_run._prune_list and pr.calculate_v_imp_score is lg_run._calculate_v_imp_score
+        assert gm.GaussianModel.prune_points is lg_run._prune_points and gm.GaussianModel.prune_gaussians is lg_run._prune_gaussians
+        assert vq.gumbel_sample is not originals["gumbel_sample"] and vq.torch is not torch and vq.torch.cdist is not torch.cdist
+        assert vq.torch.zeros is torch.zeros and vq.torch.nn is torch.nn          # everything else is torch's own
+        # the already-imported names followed (also under another name)
+        assert trainer.render is lg_gr.render and trainer.renamed_render is lg_gr.render and trainer.count_render is lg_gr.count_render
+        assert trainer.l1_loss is lg_loss.l1_loss and trainer.ssim is lg_loss.ssim
+        assert trainer.prune_list is lg_run._prune_list and trainer.calculate_v_imp_score is lg_run._calculate_v_imp_score
+        for key in ("gaussian_renderer.render", "gaussian_renderer.count_render", "utils.loss_utils.l1_loss", "utils.loss_utils.ssim", "prune.prune_list",
+                    "prune.calculate_v_imp_score", "scene.gaussian_model.GaussianModel.prune_points",
+                    "scene.gaussian_model.GaussianModel.prune_gaussians", "vectree.vq.gumbel_sample"):
+            assert key in report and "skipped" not in report[key], (key, report.get(key))
+        assert report["gaussian_renderer.render"]["also_rebound_in"] >= 2
+        assert lg_run.patch_reference() == report                                  # idempotent
+        # call contracts: the reference's positional parameters, in order, are accepted by the replacements
+        for name, new in (("render", gr.render), ("count_render", gr.count_render), ("l1_loss", lu.l1_loss), ("ssim", lu.ssim),
+                          ("prune_list", pr.prune_list), ("calculate_v_imp_score", pr.calculate_v_imp_score),
+                          ("prune_points", gm.GaussianModel.prune_points), ("prune_gaussians", gm.GaussianModel.prune_gaussians),
+                          ("gumbel_sample", vq.gumbel_sample)):
+            want, have = _positional(originals[name]), _positional(new)
+            assert have[:len(want)] == want, (name, want, have)
+            for p_old, p_new in zip(inspect.signature(originals[name]).parameters.values(), inspect.signature(new).parameters.values()):
+                if p_old.default is not inspect.Parameter.empty:
+                    assert p_new.default == p_old.default, (name, p_old.name)
+    finally:
+        lg_run.unpatch_reference()
+        del sys.modules["fake_trainer"]
+    assert gr.render is originals["render"] and gr.count_render is originals["count_render"]
+    assert lu.l1_loss is originals["l1_loss"] and lu.ssim is originals["ssim"]
+    assert pr.prune_list is originals["prune_list"] and pr.calculate_v_imp_score is originals["calculate_v_imp_score"]
+    assert gm.GaussianModel.prune_points is originals["prune_points"] and gm.GaussianModel.prune_gaussians is originals["prune_gaussians"]
+    assert vq.gumbel_sample is originals["gumbel_sample"] and vq.torch is torch
+    assert trainer.render is originals["render"] and trainer.ssim is originals["ssim"]
+
+
+def test_patched_vectree_search_leaves_cpu_and_unsupported_calls_to_torch(ref):
+    """The deferred-cdist proxy only takes over p = 2 distances of HIP float32 tensors with d <= 63; on CPU tensors the
+    reference's EuclideanCodebook.forward and kmeans() run exactly as before (same indices, same quantised rows)."""
+    *_, vq = ref
+    torch.manual_seed(0)
+    cb = vq.EuclideanCodebook(dim=12, codebook_size=64, kmeans_init=False, decay=0.8).eval()
+    x = torch.randn(1, 500, 12)
+    q0, i0 = cb(x)
+    samples = torch.randn(1, 300, 12)
+    torch.manual_seed(1); m0, b0 = vq.kmeans(samples, 16, 3)
+    lg_run.patch_reference()
+    q1, i1 = cb(x)
+    torch.manual_seed(1); m1, b1 = vq.kmeans(samples, 16, 3)
+    assert torch.equal(i0, i1) and torch.equal(q0, q1) and torch.equal(m0, m1) and torch.equal(b0, b1)
+    # the deferred object behaves like the tensor when anything but the argmax is asked of it
+    lazy = -lg_run._LazyNegDist(x[0], cb.embed[0])
+    assert torch.equal(lazy.materialize(), -torch.cdist(x[0], cb.embed[0], p=2))
+    assert lazy.shape == (500, 64)
+
+
+def test_runner_command_line_sets_up_the_path_like_python_does(tmp_path, monkeypatch):
+    script = tmp_path / "trainer.py"
+    script.write_text("import sys, json\nimport diff_gaussian_rasterization as d\nprint(json.dumps({'argv': sys.argv[1:], 'p0': sys.path[0], 'shim': d.__file__}))\n")
+    import subprocess
+    import json
+    out = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--no-patch", str(script), "-s", "scene", "--iterations", "3"],
+                         capture_output=True, text=True, cwd=dropin_common.ROOT, check=True).stdout.strip().splitlines()[-1]
+    rec = json.loads(out)
+    assert rec["argv"] == ["-s", "scene", "--iterations", "3"] and rec["p0"] == str(tmp_path)
+    assert rec["shim"].startswith(dropin_common.ROOT)
+    bad = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--frobnicate", str(script)], capture_output=True, text=True, cwd=dropin_common.ROOT)
+    assert bad.returncode != 0 and "unknown option" in bad.stderr

@@ -63,3 +63,39 @@ def test_back_to_back_sorts_on_one_stream_and_bad_arguments():
     lib = _lib.load()
     assert lib.lg_debug_sort_keys(10, keys.data_ptr(), a.data_ptr(), 5, 5, keys.data_ptr(), None) == _lib.LG_ERR_INVALID_ARGUMENT
     assert lib.lg_debug_sort_keys(0, None, None, 0, 8, None, None) == _lib.LG_OK
+
+
+def test_a_look_back_that_gives_up_is_reported_not_passed_on():
+    """r2 verdict / ADVICE: when a look-back exhausts its poll budget the pass used to continue with a wrong exclusive prefix -- a
+    silently mis-sorted key array.  lg_debug_sort_orphan runs one digit pass whose only tile has a predecessor that never
+    publishes (ticket preset to 1): the kernel must come back (no hang) with the error word set, surfaced as LG_ERR_DEVICE.
+    (In a view the same bit lands in the abort word counters[0]: lg_tile_ranges and the blend kernels leave the view empty and
+    LG_FLAG_DEBUG / lg_view_status() report it.)"""
+    lib = _lib.load()
+    n = 5000
+    keys = torch.randint(0, 2 ** 40, (n,), generator=torch.Generator().manual_seed(3), dtype=torch.int64).to(DEV)
+    pad = torch.zeros(8192 + n, dtype=torch.int64, device=DEV)       # the pass addresses its tile as tile 1: room below the keys
+    pad[8192:] = keys
+    out = torch.zeros_like(pad)
+    temp = torch.empty(lib.lg_debug_sort_temp_bytes(2 * 8192), dtype=torch.uint8, device=DEV)
+    rc = lib.lg_debug_sort_orphan(n, pad[8192:].data_ptr(), out[8192:].data_ptr(), temp.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == _lib.LG_ERR_DEVICE and b"look-back gave up" in lib.lg_last_error()
+    torch.cuda.synchronize()
+    # and the healthy path still reports success on the same buffers
+    good = _sort(keys, 0, 40)
+    assert torch.equal(good, torch.sort(keys).values)
+
+
+def test_view_status_reads_the_abort_word_of_a_healthy_view():
+    import math
+    from lightgaussian_amd import synthetic as syn
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device(DEV)
+    pc = syn.make_gaussians(20000, seed=3, log_scale_mean=math.log(0.02)).to(dev).requires_grad_(True)
+    cam = syn.orbit_camera(0, 8, 320, 200).to(dev)
+    img = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))["render"]
+    geom = img.grad_fn.saved_tensors[-3]
+    words = (C.c_uint32 * 4)()
+    lib = _lib.load()
+    _lib.check(lib.lg_view_status(geom.data_ptr(), 20000, C.byref(words), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert words[0] == 0 and words[3] > 0 and words[3] == _lib.last_stats()["num_rendered"]

@@ -223,3 +223,55 @@ def test_a_whole_training_step_is_graph_capturable():
         for n, r in zip(names, ref[4][1]):
             assert torch.equal(getattr(pc, n).grad, r), (kind, "recapture", n)
     assert held.grad_fn is not None
+
+
+def test_a_prune_pass_on_one_thread_and_renders_on_another_do_not_disturb_each_other():
+    """r2 verdict: prune_list_sharded / _ViewRunner used to flip module-level switches (skip_color_in_count, sync_free) while they
+    ran: a render() issued by another thread meanwhile came back as uninitialised memory or took another forward mode.  The
+    switches are per call / per thread now: both threads get exactly what they get alone, and the process defaults stay put."""
+    import threading
+    rasterizer.set_option("sync_free", "validated")                # the shipped default
+    g, cams, pipe, bg = _scene(N=40000, W=480, H=320, scale=0.02)
+    views = cams * 6
+    with torch.no_grad():
+        ref_cnt, ref_imp = prune.prune_list_sharded(g, views, pipe, bg, streams=3, block=5)
+        ref_img = [render(c, g, pipe, bg)["render"].clone() for c in cams]
+        ref_cr = [count_render(c, g, pipe, bg)["render"].clone() for c in cams]
+    defaults = dict(rasterizer._OPTIONS)
+    out, errors, stop = {}, [], threading.Event()
+
+    def pruner():
+        try:
+            torch.cuda.set_device(DEV)
+            res = []
+            with torch.no_grad():
+                for _ in range(4):
+                    res.append(prune.prune_list_sharded(g, views, pipe, bg, streams=3, block=5))
+            out["prune"] = res
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+        finally:
+            stop.set()
+
+    t = threading.Thread(target=pruner)
+    t.start()
+    imgs, crs, n = [], [], 0
+    with torch.no_grad():
+        while not stop.is_set() or n < len(cams):
+            k = n % len(cams)
+            imgs.append((k, render(cams[k], g, pipe, bg)["render"]))
+            crs.append((k, count_render(cams[k], g, pipe, bg)["render"]))      # a count render that DOES want its image
+            assert rasterizer._OPTIONS == defaults                              # nobody switched anything under our feet
+            n += 1
+            if n > 400:
+                break
+    t.join()
+    assert not errors, errors
+    assert n >= len(cams)
+    for k, im in imgs:
+        assert torch.equal(im, ref_img[k]), f"render() of view {k} changed while a prune pass ran on another thread"
+    for k, im in crs:
+        assert torch.equal(im, ref_cr[k]), f"count_render() image of view {k} changed while a prune pass ran on another thread"
+    for cnt, imp in out["prune"]:
+        assert torch.equal(cnt, ref_cnt) and torch.equal(imp, ref_imp)
+    assert rasterizer._OPTIONS == defaults and rasterizer.pending_status() == []
