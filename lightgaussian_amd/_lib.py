@@ -20,7 +20,7 @@ LG_ERR_PREFILTERED = -4
 
 WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
 FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_L1_ONLY = 1, 2, 4, 8, 16, 32
-FLAG_PAIR_SORT, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
+FLAG_NARROW_KEY, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",

@@ -102,12 +102,19 @@ struct PinnedSlot {
         }                                                                                    \
     } while (0)
 
-// Layout of the sort key of one view: tile | (depth bits - bias) | Gaussian id.  Exact forward: from the read-back depth
-// maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
+// Layout of the sort key of one view: tile | (depth bits - bias) >> store_drop | Gaussian id.  Exact forward: from the
+// read-back depth maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
 #ifndef LG_MIN_DEPTH_BITS
 #define LG_MIN_DEPTH_BITS 18
 #endif
-struct KeyPlan { bool packed; int tile_bits, gid_bits, depth_bits, drop; uint32_t gid_mask; };
+#define LG_NARROW_KEY_BITS 40   // LG_FLAG_NARROW_KEY (cross-check): lay the key out as if only this many bits were available
+struct KeyPlan {
+    int tile_bits, gid_bits, depth_bits;   // field widths; depth_bits = width of the FULL depth pattern (minus bias) of this view
+    int store_drop;                        // low depth bits that are not stored in the key (the fields exceed 64 bits): 0 at C3
+    int drop;                              // low STORED depth bits the radix passes skip; lg_tile_ranges finishes drop + store_drop bits
+    uint32_t gid_mask;
+    int stored() const { return depth_bits - store_drop; }
+};
 static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t flags)
 {
     KeyPlan k;
@@ -115,15 +122,20 @@ static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t fla
     k.gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
     const uint32_t dspan = dmax_bits > LG_DEPTH_BIAS ? dmax_bits - LG_DEPTH_BIAS : 0u;
     k.depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
-    k.packed = (k.tile_bits + k.depth_bits + k.gid_bits <= 64) && !(flags & LG_FLAG_PAIR_SORT);
-    // The radix sort works in 8-bit passes.  The lowest `drop` depth bits are left to lg_tile_ranges (runs of equal sorted
-    // bits are finished there by insertion) whenever that saves whole passes and at least LG_MIN_DEPTH_BITS depth bits
-    // (sign-free float pattern: exponent + >= 13 mantissa bits at scene depths) stay in the sort: 39 -> 32 sorted bits at
-    // C3 (exact forward, 26 depth bits), 40 -> 32 in the bounded forward (27 bits for a zfar of 100).
+    // The three fields must fit 64 bits.  When they do not (6 M Gaussians at 3840x2160: 15 + 27 + 23 = 65; 20 M at 1080p; ...)
+    // the lowest depth bits are left out of the key and lg_tile_ranges completes the order from the full depth pattern in the
+    // binning record (tinfo) -- r2 fell back to a (tile << 32 | depth, id) pair sort through hipCUB there, without the bounded
+    // forward, the graph and the fused histograms.  At least one depth bit is always stored (tile <= 32 bits, id <= 29).
+    const int avail = (flags & LG_FLAG_NARROW_KEY) ? LG_NARROW_KEY_BITS : 64;
+    k.store_drop = std::max(0, std::min(k.depth_bits - 1, k.tile_bits + k.depth_bits + k.gid_bits - avail));
+    // The radix sort works in 8-bit passes.  The lowest `drop` stored depth bits are left to lg_tile_ranges as well whenever that
+    // saves whole passes and at least LG_MIN_DEPTH_BITS depth bits (sign-free float pattern: exponent + >= 13 mantissa bits at
+    // scene depths) stay in the sort: 39 -> 32 sorted bits at C3 (exact forward, 26 depth bits), 40 -> 32 in the bounded
+    // forward (27 bits for a zfar of 100).
     k.drop = 0;
-    if (k.packed && !(flags & LG_FLAG_SORT_ALL_BITS)) {
-        const int sorted = k.tile_bits + k.depth_bits;
-        for (int d = sorted % 8; d <= k.depth_bits - LG_MIN_DEPTH_BITS; d += 8) k.drop = d;   // the largest admissible
+    if (!(flags & LG_FLAG_SORT_ALL_BITS)) {
+        const int sorted = k.tile_bits + k.stored();
+        for (int d = sorted % 8; d <= k.stored() - LG_MIN_DEPTH_BITS; d += 8) k.drop = d;   // the largest admissible
     }
     k.gid_mask = k.gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << k.gid_bits) - 1u);
     return k;
@@ -161,9 +173,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (!bounded->binning || bounded->capacity <= 0 || bounded->capacity >= (1ll << 30) || !(bounded->max_depth > 0.2f))
             return fail(LG_ERR_INVALID_ARGUMENT, "lg_forward_bounded: binning buffer, 0 < max_rendered < 2^30 and max_depth > 0.2 required");
         kp = make_key_plan(ntiles, N, __builtin_bit_cast(uint32_t, bounded->max_depth), v->flags);
-        if (!kp.packed) return fail(LG_ERR_INVALID_ARGUMENT, "lg_forward_bounded: tile | depth | id exceed 64 key bits; use lg_forward");
         cap = bounded->capacity;
-        bin = carve_bin(bounded->binning, cap, W, H, true, S);
+        bin = carve_bin(bounded->binning, cap, W, H, S);
         if (binning_out) *binning_out = bounded->binning;
         if (num_rendered) *num_rendered = cap;
         if (N == 0) {
@@ -221,10 +232,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         R = h_counters[3];
         if (R >= (1ll << 30)) return fail(LG_ERR_INVALID_ARGUMENT, "more than 2^30-1 tile instances in one view");
         kp = make_key_plan(ntiles, N, h_counters[2], v->flags);
-        void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, kp.packed, S).total);
+        void* bin_p = alloc(alloc_user, carve_bin(nullptr, R, W, H, S).total);
         if (!bin_p) return fail(LG_ERR_ALLOC, "binning allocator returned NULL");
         if (binning_out) *binning_out = bin_p;
-        bin = carve_bin(bin_p, R, W, H, kp.packed, S);
+        bin = carve_bin(bin_p, R, W, H, S);
         cap = R;
         if (num_rendered) *num_rendered = R;
         if (R == 0) HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
@@ -242,44 +253,30 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     g_stats.num_rendered = bounded ? -1 : R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
 
-    const int sort_begin = kp.gid_bits + kp.drop, sort_end = kp.gid_bits + kp.depth_bits + kp.tile_bits;
+    const int sort_begin = kp.gid_bits + kp.drop, sort_end = kp.gid_bits + kp.stored() + kp.tile_bits;
     if (cap > 0 && N > 0) {
         const LgSortLayout SL = lg_sort_layout((size_t)cap);
-        uint32_t* hist = nullptr;
-        if (kp.packed) {
-            // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass
-            HIP_TRY(lg_zero_async(bin.sort_temp, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
-            hist = (uint32_t*)((char*)bin.sort_temp + SL.hist_off);
-        }
+        // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass
+        HIP_TRY(lg_zero_async(bin.sort_temp, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
+        uint32_t* hist = (uint32_t*)((char*)bin.sort_temp + SL.hist_off);
         {
             ProfScope ps(prof, "duplicate", stream);
             const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), LG_DUP_GRID));
-            if (kp.packed)
-                lg_duplicate<true><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.depth_bits, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
-                                                              geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, nullptr, ntiles, bin.ranges, hist);
-            else
-                lg_duplicate<false><<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, 0, 0, 0, 0, (uint32_t)cap, geo.touched, geo.blk_off, geo.part_prefix, geo.counters, geo.offsets,
-                                                               geo.tinfo, bin.keys_in, bin.vals_in, ntiles, bin.ranges, nullptr);
+            lg_duplicate<<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.stored(), kp.store_drop, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
+                                                              geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, ntiles, bin.ranges, hist);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
-            if (kp.packed)
-                HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (uint32_t)cap, sort_begin, sort_end, geo.counters, true, stream));
-            else
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin.sort_temp, tb, bin.keys_in, bin.keys_tmp, bin.vals_in, bin.vals_out, (int)R, 0,
-                                                           32 + kp.tile_bits, stream));
+            HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (uint32_t)cap, sort_begin, sort_end, geo.counters, true, stream));
         }
         KCHECK("lg_sort_keys");
         {
             ProfScope ps(prof, "tile_ranges", stream);
             const uint32_t rgrid = (uint32_t)((cap + 255) / 256);
-            if (kp.packed)
-                lg_tile_ranges<true><<<rgrid, 256, 0, stream>>>(geo.counters, kp.depth_bits + kp.gid_bits, kp.gid_bits, kp.drop,
-                                                                bin.entries, nullptr, bin.entries, bin.keys_in, bin.ranges);
-            else
-                lg_tile_ranges<false><<<rgrid, 256, 0, stream>>>(geo.counters, 32, 0, 0, bin.keys_tmp, bin.vals_out, bin.entries, nullptr, bin.ranges);
+            lg_tile_ranges<<<rgrid, 256, 0, stream>>>(geo.counters, kp.stored() + kp.gid_bits, kp.gid_bits, kp.gid_mask, kp.drop, kp.store_drop,
+                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges);
         }
         KCHECK("lg_tile_ranges");
     }
@@ -392,7 +389,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
     ImgView img = carve_img(const_cast<void*>(img_p), W, H);
     const int S = lg_segment_of(v);   // must be the forward's (same lg_view); the kernels compare it with meta[2] and refuse otherwise
-    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, true, S); // only the format-independent prefix is used
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, S);
     const int gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));          // same field width as the forward used
     const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
     float* rows = (float*)scratch; // [R][12] gradient rows, every row written by lg_blend_bwd

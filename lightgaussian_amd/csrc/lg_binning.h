@@ -118,9 +118,11 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 }
 
 // K3: duplicate with keys
-// Key formats.  PACKED: tile | (depth bits - bias) | Gaussian id in one u64, sorted keys-only on the tile+depth
-// bits: the stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free.
-// PAIRS (fallback when the fields do not fit 64 bits): tile<<32 | depth with the Gaussian id as value.
+// Key format: tile | (depth bits - bias) >> store_drop | Gaussian id in one u64, sorted keys-only on the tile + depth bits: the
+// stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free.  store_drop > 0 only
+// when tile + depth + id exceed 64 bits (6 M Gaussians at 4K, 20 M at 1080p, ...): the lowest depth bits are then not STORED
+// at all and lg_tile_ranges finishes the order from the full depth in tinfo (no pair format, no library sort: the former
+// (tile << 32 | depth, id) fallback through hipCUB is gone).
 //
 // Wave-cooperative expansion: a wave takes the 64 Gaussians of one K1 workgroup, scans their instance counts, and then
 // LANE l WRITES INSTANCE p = 64 c + l of the wave (c = 0, 1, ...), finding its Gaussian by a 6-step binary search over
@@ -137,26 +139,23 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 #define LG_DUP_GRID 512        // workgroups (two per CU; 256: 0.050 ms, 512: 0.044 ms at C3)
 #endif
 #define LG_DUP_WAVES (LG_DUP_THREADS / 64)
-template <bool PACKED>
 __global__ void __launch_bounds__(LG_DUP_THREADS)
-lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
+lg_duplicate(int N, int nblk, int gx, int stored_depth_bits, int store_drop, int gid_bits, int sort_begin, int sort_end, uint32_t capacity,
              const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ part_prefix,
              const uint32_t* __restrict__ counters,
-             uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+             uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys,
              int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t lh[PACKED ? LG_SORT_MAX_PASSES * 256 : 1];
+    __shared__ uint32_t lh[LG_SORT_MAX_PASSES * 256];
     __shared__ uint32_t s_exc[LG_DUP_WAVES][64], s_xy[LG_DUP_WAVES][64], s_w[LG_DUP_WAVES][64], s_hi[LG_DUP_WAVES][64], s_lo[LG_DUP_WAVES][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // empty tiles keep {0, 0}: cleared here (this kernel runs before the sort) instead of by a memset
     for (int t = blockIdx.x * LG_DUP_THREADS + (int)tid; t < ntiles; t += gridDim.x * LG_DUP_THREADS) ranges[t] = make_uint2(0u, 0u);
-    const int passes = PACKED ? (sort_end - sort_begin + 7) / 8 : 0;
-    if (PACKED) {
-        for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS) lh[i] = 0;
-        __syncthreads();
-    }
+    const int passes = (sort_end - sort_begin + 7) / 8;
+    for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS) lh[i] = 0;
+    __syncthreads();
     if (counters[0] != 0u) return;                 // view aborted by lg_scan_blocks (capacity-bounded forward)
-    const int sh = depth_bits + gid_bits;
+    const int sh = stored_depth_bits + gid_bits;
     // a wave takes FOUR consecutive K1 workgroups per iteration and issues all of their loads (instance counts, base offsets,
     // tile rectangles) before it touches any of them: one exposed memory round trip per 256 Gaussians instead of two per 64
     // (the first version, one K1 workgroup per iteration with dependent loads, was latency-bound: 61 us at C3)
@@ -195,14 +194,9 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
                 s_exc[wave][lane] = exc;
                 s_xy[wave][lane] = r.x;
                 s_w[wave][lane] = (r.y & 0xFFFFu) - (r.x & 0xFFFFu);
-                if (PACKED) {
-                    const uint64_t low = ((uint64_t)(r.z - LG_DEPTH_BIAS) << gid_bits) | (uint32_t)i;
-                    s_lo[wave][lane] = (uint32_t)low;
-                    s_hi[wave][lane] = (uint32_t)(low >> 32);
-                } else {
-                    s_lo[wave][lane] = r.z;                    // depth bits
-                    s_hi[wave][lane] = (uint32_t)i;            // value = Gaussian id
-                }
+                const uint64_t low = ((uint64_t)((r.z - LG_DEPTH_BIAS) >> store_drop) << gid_bits) | (uint32_t)i;
+                s_lo[wave][lane] = (uint32_t)low;
+                s_hi[wave][lane] = (uint32_t)(low >> 32);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -215,27 +209,20 @@ lg_duplicate(int N, int nblk, int gx, int depth_bits, int gid_bits, int sort_beg
                     const uint32_t ky = k / w, kx = k - ky * w;
                     const uint32_t tile = ((xy >> 16) + ky) * (uint32_t)gx + (xy & 0xFFFFu) + kx;
                     const uint64_t pos = (uint64_t)base + p;
-                    if (PACKED) {
-                        const uint64_t key = ((uint64_t)tile << sh) | ((uint64_t)s_hi[wave][j] << 32) | s_lo[wave][j];
-                        if (pos < capacity) keys[pos] = key;
-                        for (int q = 0; q < passes; q++) {
-                            const int bit = sort_begin + 8 * q, nb = min(8, sort_end - bit);
-                            atomicAdd(&lh[q * 256 + (uint32_t)((key >> bit) & ((1u << nb) - 1u))], 1u);
-                        }
-                    } else if (pos < capacity) {
-                        keys[pos] = ((uint64_t)tile << 32) | s_lo[wave][j];
-                        vals[pos] = s_hi[wave][j];
+                    const uint64_t key = ((uint64_t)tile << sh) | ((uint64_t)s_hi[wave][j] << 32) | s_lo[wave][j];
+                    if (pos < capacity) keys[pos] = key;
+                    for (int q = 0; q < passes; q++) {
+                        const int bit = sort_begin + 8 * q, nb = min(8, sort_end - bit);
+                        atomicAdd(&lh[q * 256 + (uint32_t)((key >> bit) & ((1u << nb) - 1u))], 1u);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();               // the next K1 workgroup overwrites this wave's LDS rows
             }
         }
     }
-    if (PACKED) {
-        __syncthreads();
-        for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS)
-            if (lh[i]) atomicAdd(&hist[i], lh[i]);
-    }
+    __syncthreads();
+    for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 // Pre-sort slot of the instance of Gaussian `gid` in tile (tx, ty): lg_duplicate emits a Gaussian's instances row by row
@@ -246,71 +233,135 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
     return r.w + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
 }
 
-// K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised in the packed
-// format -- the blend kernels read the sorted keys themselves).  Pairs format: also writes entries[i] = Gaussian id.
-//
-// DROP > 0 (packed format only): the radix sort skipped the lowest `drop` depth bits to save a whole 8-bit pass
-// (39 -> 32 sorted bits at C3: 5 -> 4 passes).  Entries that agree on the sorted bits form short runs (depth agrees to
-// 2^-16 relative within one tile: about one pair per tile) which are still in emission order; the first thread of each
-// run finishes the job with a stable insertion sort (merge sort beyond 32 entries) on the full tile | depth field.  The result is exactly the
-// order a sort over all bits gives (stable => id order among equal depths).  Other threads may read a key of the run
-// while it moves: they only look at its tile field, which all members share.
-template <bool PACKED>
-__global__ void __launch_bounds__(256)
-lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, int drop, const uint64_t* keys /* == entries in the packed format */,
-               const uint32_t* __restrict__ vals_sorted, uint64_t* entries, uint64_t* scratch, uint2* __restrict__ ranges)
+// K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised -- the blend kernels read
+// the sorted keys themselves) and completion of the order on the depth bits the radix sort did not cover:
+//   drop        low STORED depth bits the radix passes skipped to save a whole 8-bit pass (39 -> 32 sorted bits at C3: 5 -> 4)
+//   store_drop  low depth bits that are not in the key at all (tile + depth + id beyond 64 bits): read from tinfo[id].z
+// Entries that agree on the sorted bits form runs that are still in emission (= id) order; ordering a run stably on its
+// low = drop + store_drop depth bits gives exactly the order a sort over all bits gives.  Short runs (<= 32 entries; depth
+// agrees to 2^-13 relative within one tile: about one pair per tile) are finished by their first thread with a stable
+// insertion sort.  LONG runs -- a slab of coplanar splats puts thousands of entries at one depth; a narrow key (store_drop)
+// makes every run longer -- are finished by the WHOLE WAVE of the thread that found them: a stable LSD counting sort over the
+// low bits, 8 bits per pass (LDS digit counters, ballot-matched ranks, ping-pong with the free radix-sort input buffer), the
+// wave serving its long runs one at a time.  (r2 used a single-thread merge sort there: 14.8 ms when the runs got long.)
+// Other threads may read a key of a run while it moves: they only look at its tile field, which all members share.
+#define LG_RUN_SHORT 32u
+__device__ __forceinline__ uint32_t lg_low_bits(uint64_t key, int gid_bits, uint32_t gid_mask, int store_drop, uint32_t low_mask,
+                                                const uint4* __restrict__ tinfo)
 {
-    if (counters[0] != 0u) return;                 // view aborted (capacity-bounded forward)
-    const uint32_t R = counters[3];                // the grid is sized for the capacity; the instance count lives on the device
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const uint64_t key = keys[i];
-    const uint32_t t = (uint32_t)(key >> tile_shift);
-    if (!PACKED) entries[i] = (uint64_t)vals_sorted[i];
-    uint64_t prev = 0;
-    if (i == 0) ranges[t].x = 0;
-    else {
-        prev = keys[i - 1];
-        const uint32_t tp = (uint32_t)(prev >> tile_shift);
-        if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
-    }
-    if (i == R - 1) ranges[t].y = R;
-    if (PACKED && drop > 0) {
-        const int fs = gid_bits + drop;
-        if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal sorted bits
-            uint32_t e = i + 1;
-            while (e < R && (keys[e] >> fs) == (key >> fs)) e++;
-            if (e - i <= 32u) {
-                for (uint32_t a = i + 1; a < e; a++) {           // stable insertion sort of [i, e) on tile | depth
-                    const uint64_t k = entries[a];
-                    uint32_t b = a;
-                    while (b > i && (entries[b - 1] >> gid_bits) > (k >> gid_bits)) { entries[b] = entries[b - 1]; b--; }
-                    if (b != a) entries[b] = k;
-                }
-            } else {
-                // a long run (a slab of Gaussians within 2^-16 of one depth): bottom-up stable merge sort, O(n log n),
-                // ping-ponging with the same range of the (now free) radix-sort input buffer
-                uint64_t* src = entries; uint64_t* dst = scratch;
-                for (uint32_t w = 1; w < e - i; w <<= 1) {
-                    for (uint32_t lo = i; lo < e; lo += 2 * w) {
-                        const uint32_t mid = min(lo + w, e), hi = min(lo + 2 * w, e);
-                        uint32_t a = lo, b = mid, o = lo;
-                        while (a < mid && b < hi) {
-                            const uint64_t ka = src[a], kb = src[b];
-                            if ((kb >> gid_bits) < (ka >> gid_bits)) { dst[o++] = kb; b++; } else { dst[o++] = ka; a++; }
-                        }
-                        while (a < mid) dst[o++] = src[a++];
-                        while (b < hi) dst[o++] = src[b++];
-                    }
-                    uint64_t* t = src; src = dst; dst = t;
-                }
-                if (src != entries)
-                    for (uint32_t a = i; a < e; a++) entries[a] = src[a];
+    if (store_drop == 0) return (uint32_t)(key >> gid_bits) & low_mask;          // wave-uniform branch
+    return (tinfo[(uint32_t)key & gid_mask].z - LG_DEPTH_BIAS) & low_mask;        // the full depth pattern, from the binning record
+}
+
+// stable LSD counting sort of entries[i, e) on the low_bits low depth bits, by one wave (all lanes with i < R active)
+__device__ __forceinline__ void lg_wave_sort_run(uint32_t i, uint32_t e, int low_bits, int gid_bits, uint32_t gid_mask, int store_drop,
+                                                 uint64_t* entries, uint64_t* scratch, const uint4* __restrict__ tinfo, uint32_t* cnt /* LDS [256] */,
+                                                 uint32_t lane)
+{
+    const uint32_t low_mask = low_bits >= 32 ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
+    uint64_t* src = entries;
+    uint64_t* dst = scratch;
+    for (int shift = 0; shift < low_bits; shift += 8) {
+        const uint32_t dmask = (1u << min(8, low_bits - shift)) - 1u;
+        for (uint32_t c = lane; c < 256u; c += 64u) cnt[c] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t a = i + lane; a < e; a += 64u)
+            atomicAdd(&cnt[(lg_low_bits(src[a], gid_bits, gid_mask, store_drop, low_mask, tinfo) >> shift) & dmask], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // exclusive scan of the 256 counters: lane l owns digits 4 l .. 4 l + 3
+            const uint32_t c0 = cnt[4u * lane], c1 = cnt[4u * lane + 1u], c2 = cnt[4u * lane + 2u], c3 = cnt[4u * lane + 3u];
+            uint32_t inc = c0 + c1 + c2 + c3;
+            const uint32_t own = inc;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const uint32_t o = __shfl_up(inc, s, 64);
+                if ((int)lane >= s) inc += o;
             }
+            const uint32_t ex = inc - own;
+            cnt[4u * lane] = ex; cnt[4u * lane + 1u] = ex + c0; cnt[4u * lane + 2u] = ex + c0 + c1; cnt[4u * lane + 3u] = ex + c0 + c1 + c2;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t a0 = i; a0 < e; a0 += 64u) {              // in list order: lanes of one digit keep their relative order
+            const uint32_t a = a0 + lane;
+            const bool valid = a < e;
+            const uint64_t k = valid ? src[a] : 0ull;
+            const uint32_t d = valid ? (lg_low_bits(k, gid_bits, gid_mask, store_drop, low_mask, tinfo) >> shift) & dmask : 0u;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t below = prefix_popc(peers);
+            uint32_t pos = 0;
+            if (valid) pos = cnt[d] + below;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (valid && below == 0u) cnt[d] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (valid) dst[i + pos] = k;
+        }
+        __threadfence();                                        // the next pass (other lanes) reads what this one wrote
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    if (src != entries) {
+        for (uint32_t a = i + lane; a < e; a += 64u) entries[a] = src[a];
+        __threadfence();
     }
 }
 
+__global__ void __launch_bounds__(256)
+lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, uint32_t gid_mask, int drop, int store_drop,
+               uint64_t* entries /* the sorted keys */, uint64_t* scratch, const uint4* __restrict__ tinfo, uint2* __restrict__ ranges)
+{
+    __shared__ uint32_t s_cnt[4][256];
+    if (counters[0] != 0u) return;                 // view aborted (capacity-bounded forward, or the sort's look-back gave up)
+    const uint32_t R = counters[3];                // the grid is sized for the capacity; the instance count lives on the device
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int low_bits = drop + store_drop;
+    bool mylong = false;
+    uint32_t run_end = 0;
+    if (i < R) {
+        const uint64_t key = entries[i];
+        const uint32_t t = (uint32_t)(key >> tile_shift);
+        uint64_t prev = 0;
+        if (i == 0) ranges[t].x = 0;
+        else {
+            prev = entries[i - 1];
+            const uint32_t tp = (uint32_t)(prev >> tile_shift);
+            if (t != tp) { ranges[tp].y = i; ranges[t].x = i; }
+        }
+        if (i == R - 1) ranges[t].y = R;
+        if (low_bits > 0) {
+            const int fs = gid_bits + drop;
+            if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal sorted bits
+                uint32_t e = i + 1;
+                while (e < R && (entries[e] >> fs) == (key >> fs)) e++;
+                if (e - i > LG_RUN_SHORT) { mylong = true; run_end = e; }
+                else if (e - i > 1u) {
+                    const uint32_t low_mask = low_bits >= 32 ? 0xFFFFFFFFu : ((1u << low_bits) - 1u);
+                    for (uint32_t a = i + 1; a < e; a++) {           // stable insertion sort of [i, e) on the low depth bits
+                        const uint64_t k = entries[a];
+                        const uint32_t lk = lg_low_bits(k, gid_bits, gid_mask, store_drop, low_mask, tinfo);
+                        uint32_t b = a;
+                        while (b > i && lg_low_bits(entries[b - 1], gid_bits, gid_mask, store_drop, low_mask, tinfo) > lk) { entries[b] = entries[b - 1]; b--; }
+                        if (b != a) entries[b] = k;
+                    }
+                }
+            }
+        }
+    }
+    // long runs: one at a time, by the whole wave (lanes beyond R idle along: every wave-level operation below is executed by
+    // all 64 lanes)
+    uint64_t big = __ballot(mylong);
+    while (big) {
+        const int srcl = (int)__builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)i, srcl), re = (uint32_t)__builtin_amdgcn_readlane((int)run_end, srcl);
+        lg_wave_sort_run(ri, re, low_bits, gid_bits, gid_mask, store_drop, entries, scratch, tinfo, s_cnt[wave], lane);
+    }
+}
 
 // Work list of the backward blend: one item per (tile, segment of S list entries), longest first.  The backward runs one
 // wave per item and only ~1.6 items per wave slot, so which items share a slot decides the makespan: handing out the long

@@ -145,9 +145,8 @@ static ImgView carve_img(void* base, int W, int H)
     return v;
 }
 
-// Binning buffer.  The first three arrays are what the blend kernels and the backward read; they sit at the same
-// offsets for both key formats.  There is no separate id list and no slot list: the id is the low field of the sorted
-// key, and the pre-sort slot (row address of the backward) is recomputed from the Gaussian's tile rectangle (tinfo).
+// Binning buffer.  There is no separate id list and no slot list: the id is the low field of the sorted key, and the pre-sort
+// slot (row address of the backward) is recomputed from the Gaussian's tile rectangle (tinfo).
 // Long per-tile lists (real captures: tens of thousands of entries on a few tiles) are cut into SEGMENTS of S entries
 // (lg_view.segment_length, default LG_DEFAULT_SEGMENT): the forward leaves one checkpoint record per pixel at the end of every
 // segment of such a tile, and the backward runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry
@@ -169,11 +168,8 @@ struct BinView {
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
     uint32_t* ckpt_last;            // [2 (R / S + 1)][256] last contributing list position per (segment, pixel): pass 1 -> join of
                                     //     the parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk)
-    uint64_t* entries;              // [R] sorted list entries; the low bits_for(N) bits are the Gaussian id.  Packed format:
-                                    //     these ARE the sorted keys (tile | depth | id).  Pairs format: written by lg_tile_ranges
-    uint64_t* keys_in;              // [R] radix-sort input
-    uint64_t* keys_tmp;             // [R] (pairs format only) sorted keys
-    uint32_t *vals_in, *vals_out;   // [R] (pairs format only) Gaussian ids carried through the sort
+    uint64_t* entries;              // [R] sorted list entries = the sorted keys (tile | depth | id); the low bits_for(N) bits are the Gaussian id
+    uint64_t* keys_in;              // [R] radix-sort input; free after the sort: ping-pong buffer of lg_tile_ranges' long runs
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
 static int bits_for(uint32_t n) // smallest b with 2^b >= n
@@ -182,7 +178,7 @@ static int bits_for(uint32_t n) // smallest b with 2^b >= n
     while (b < 32 && (1ull << b) < n) b++;
     return b;
 }
-static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed, int seg)
+static BinView carve_bin(void* base, int64_t R, int W, int H, int seg)
 {
     BinView v; memset(&v, 0, sizeof(v)); size_t off = 0; char* p = (char*)base;
     auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
@@ -197,16 +193,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, bool packed, int s
     v.ckpt_last = (uint32_t*)take(2 * (n / S + 1) * 256 * 4);
     v.entries = (uint64_t*)take(n * 8);
     v.keys_in = (uint64_t*)take(n * 8);
-    size_t tb = 0;
-    if (packed) {
-        tb = lg_sort_layout(n).total;
-    } else {
-        v.keys_tmp = (uint64_t*)take(n * 8);
-        v.vals_in = (uint32_t*)take(n * 4);
-        v.vals_out = (uint32_t*)take(n * 4);
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                                 (uint32_t*)nullptr, (int)n, 0, 64);
-    }
+    const size_t tb = lg_sort_layout(n).total;
     v.sort_temp_bytes = tb;
     v.sort_temp = take(tb);
     v.total = off;
@@ -218,8 +205,7 @@ extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr,
 extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H, int32_t segment_length)
 {
     if (segment_length != 0 && (segment_length < 64 || segment_length % 64 != 0)) return 0;   // (lg_forward rejects such a view)
-    const size_t a = carve_bin(nullptr, R, W, H, true, segment_length).total, b = carve_bin(nullptr, R, W, H, false, segment_length).total;
-    return a > b ? a : b; // upper bound over both key formats
+    return carve_bin(nullptr, R, W, H, segment_length).total;
 }
 extern "C" size_t lg_backward_scratch_bytes(int32_t N, int64_t R)
 {

@@ -217,8 +217,8 @@ class _Call:
         flags |= {"serial": _lib.FLAG_LONG_SERIAL, "auto": 0, "parallel": _lib.FLAG_LONG_PARALLEL}[opts["long_tiles"]]
         # cross-check switches (tests toggle these environment variables at run time)
         env = os.environ
-        if "LG_FORCE_PAIR_SORT" in env:
-            flags |= _lib.FLAG_PAIR_SORT
+        if "LG_NARROW_KEY" in env:
+            flags |= _lib.FLAG_NARROW_KEY
         if "LG_SORT_ALL_BITS" in env:
             flags |= _lib.FLAG_SORT_ALL_BITS
         if "LG_K1_LDS" in env:
@@ -333,8 +333,6 @@ def _native_forward(lib, call, rs, count):
     mode = opts["sync_free"]
     S = int(opts["segment_length"])
     cap = _CAPACITY.get(key) if (mode and N > 0 and not rs.prefiltered) else None
-    if call.view.flags & _lib.FLAG_PAIR_SORT:
-        cap = None                                 # the pair key format (cross-check switch / fields beyond 64 bits) has no bounded form
     if cap is not None and cap > 0:          # (-1: a depth beyond max_depth was seen for this shape -> exact path for good)
         binning = torch.empty(lib.lg_binning_bytes(cap, W, H, S), **u8)
         if mode == "validated":
@@ -344,10 +342,7 @@ def _native_forward(lib, call, rs, count):
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
                                         float(opts["max_depth"]), int(opts["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), None, C.byref(host), stream)
-            if rc == _lib.LG_ERR_INVALID_ARGUMENT and b"64 key bits" in lib.lg_last_error():
-                host[0] = 2                        # tile | depth | id do not fit one key for this shape: exact path, for good
-            else:
-                _lib.check(rc)
+            _lib.check(rc)
             if host[0] == 0:
                 _note_count(key, int(host[3]), opts)
                 return color, radii, gcount, score, geom, binning, img, cap

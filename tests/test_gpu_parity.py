@@ -123,27 +123,68 @@ def test_backward_parity_canonical_arithmetic():
         rasterizer.set_option("fast_exp", True)
 
 
-def test_packed_key_sort_equals_pair_sort_fallback():
-    """Sort key formats: packed tile|depth|id u64 keys sorted keys-only on the tile+depth bits (default) vs
-    (tile<<32|depth, slot) pairs (fallback when the fields do not fit 64 bits).  Same (tile, depth, id) order
-    => bit-identical outputs and gradients."""
+@pytest.mark.parametrize("case_id", [2, 0, 6])
+def test_keys_beyond_64_bits_give_the_same_order(case_id):
+    """When tile | depth | id exceed 64 bits (6 M Gaussians at 3840x2160, 20 M at 1080p) the lowest depth bits are left out of the
+    stored key and lg_tile_ranges completes the order from the full depth in the binning record (r2 fell back to a hipCUB pair
+    sort there, without the bounded forward).  LG_NARROW_KEY=1 lays the key out as if only 40 bits were available, which drops
+    depth bits on small scenes too: same (tile, depth, id) order => bit-identical outputs and gradients, in the exact and the
+    bounded forward."""
     import os
     import gpu_common
-    gimg = np.random.RandomState(5).randn(3, CASES[2]["H"], CASES[2]["W"]).astype(np.float32)
+    from lightgaussian_amd import rasterizer
+    case = CASES[case_id]
+    gimg = np.random.RandomState(5).randn(3, case["H"], case["W"]).astype(np.float32)
     res = {}
-    for mode in ("tile", "global"):
-        if mode == "global":
-            os.environ["LG_FORCE_PAIR_SORT"] = "1"
+    for mode in ("full", "narrow", "narrow_bounded"):
+        if mode != "full":
+            os.environ["LG_NARROW_KEY"] = "1"
+        prev = rasterizer.set_option("sync_free", "validated" if mode == "narrow_bounded" else False)
         try:
-            res[mode] = (gpu_common.hip_forward_backward(_scene(CASES[2]), count=True),
-                         gpu_common.hip_forward_backward(_scene(CASES[2]), grad_image=gimg))
+            res[mode] = (gpu_common.hip_forward_backward(_scene(case), count=True),
+                         gpu_common.hip_forward_backward(_scene(case), grad_image=gimg),
+                         gpu_common.hip_forward_backward(_scene(case), count=True))      # (second view of the shape: bounded when enabled)
         finally:
-            os.environ.pop("LG_FORCE_PAIR_SORT", None)
-    a, b = res["tile"], res["global"]
-    assert np.array_equal(a[0]["count"], b[0]["count"]) and np.array_equal(a[0]["color"], b[0]["color"])
-    assert np.array_equal(a[0]["score"], b[0]["score"])
-    for name in a[1]["grads"]:
-        assert np.array_equal(a[1]["grads"][name], b[1]["grads"][name]), name   # rows + fixed-order gather: deterministic
+            os.environ.pop("LG_NARROW_KEY", None)
+            rasterizer.set_option("sync_free", prev)
+    a = res["full"]
+    ref = oracle.forward(count=True, **_np(_scene(case)))
+    assert np.array_equal(a[0]["count"], ref.count) and np.array_equal(a[0]["color"].view(np.uint32), ref.color.view(np.uint32))
+    for mode in ("narrow", "narrow_bounded"):
+        b = res[mode]
+        for k in (0, 2):
+            assert np.array_equal(a[0]["count"], b[k]["count"]) and np.array_equal(a[0]["color"], b[k]["color"]), (mode, k)
+            assert np.array_equal(a[0]["score"], b[k]["score"]) and np.array_equal(a[0]["radii"], b[k]["radii"]), (mode, k)
+        for name in a[1]["grads"]:
+            assert np.array_equal(a[1]["grads"][name], b[1]["grads"][name]), (mode, name)   # rows + fixed-order gather: deterministic
+
+
+def test_a_slab_of_coplanar_splats_on_few_tiles_is_ordered_by_the_wave_level_run_sort():
+    """20 000 splats at ONE depth on a handful of tiles: every tile list is a single run of equal sorted bits, thousands of
+    entries long.  r2 finished such runs with one thread (merge sort; 14.8 ms when the runs got long); lg_tile_ranges now hands
+    runs beyond 32 entries to the whole wave (stable LSD counting sort on the low depth bits).  Counts, scores and image must
+    equal the oracle bit for bit, with depth bits dropped from the sort, with every bit sorted, and with the narrow key."""
+    import os
+    import gpu_common
+    N, W, H = 20000, 64, 48
+    g = syn.make_gaussians(N, seed=33, log_scale_mean=math.log(0.03), opacity_mean=-4.0, extent=(0.35, 0.25, 0.0))
+    cam = syn.orbit_camera(0, 5, W, H, radius=5.0)              # camera 0 looks along +z from (0, 0, -5): the plane z = 0 is at depth 5
+    gen = torch.Generator().manual_seed(4)
+    g._xyz[:, 2] = 0.0
+    g._xyz[::7, 2] = 3e-6 * torch.randn(g._xyz[::7].shape[0], generator=gen)        # a few within the dropped bits of the others
+    kw = common.scene_kwargs(g, cam, W, H, deg=1, bg=(0.1, 0.2, 0.3), as_torch=True)
+    ref = oracle.forward(count=True, **_np(kw))
+    assert ref.num_rendered > 20000
+    for env in ({}, {"LG_SORT_ALL_BITS": "1"}, {"LG_NARROW_KEY": "1"}):
+        os.environ.update(env)
+        try:
+            out = gpu_common.hip_forward_backward(kw, count=True)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert np.array_equal(out["count"], ref.count), env
+        assert np.array_equal(out["score"].view(np.uint32), ref.score.view(np.uint32)), env
+        assert np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32)), env
 
 
 @pytest.mark.parametrize("jitter", [0.0, 3e-6, 1e-4])
