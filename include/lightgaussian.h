@@ -286,6 +286,12 @@ size_t lg_debug_sort_temp_bytes(int64_t n);
 int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, int32_t begin_bit, int32_t end_bit, void* temp,
                        void* stream);
 
+/* diagnostics: out_ids [H*W] uint32 = Gaussian id of every pixel's last contributor (0xFFFFFFFF: none), from the buffers a forward
+ * with this view saved (geom, binning, img, num_rendered as handed to lg_backward).  n_contrib itself is a position in this
+ * library's culled tile lists and cannot be compared across implementations; the id can (tests/test_gpu_full_size.py). */
+int lg_debug_last_contributor(const lg_view* view, int32_t N, const void* geom, const void* binning, const void* img, int64_t num_rendered,
+                              uint32_t* out_ids, void* stream);
+
 /* diagnostics: the failure path of the sort's look-back -- one digit pass whose only tile has a predecessor that never publishes.
  * Must return LG_ERR_DEVICE (error word set, no hang, no silent wrong order).  temp: lg_debug_sort_temp_bytes(2 * 8192). */
 int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, void* temp, void* stream);

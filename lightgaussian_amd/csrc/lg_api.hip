@@ -727,6 +727,37 @@ extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* im
     return LG_OK;
 }
 
+// diagnostics: Gaussian id of the last contributor of every pixel (0xFFFFFFFF: none) from the state a forward saved -- the
+// implementation-independent form of n_contrib (which is a position in THIS library's culled tile lists)
+__global__ void __launch_bounds__(256)
+lg_debug_last_contributor_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint64_t* __restrict__ entries, uint32_t gid_mask,
+                                 const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ counters, uint32_t* __restrict__ out)
+{
+    const size_t pid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pid >= (size_t)W * H) return;
+    const int x = (int)(pid % (size_t)W), y = (int)(pid / (size_t)W);
+    const uint32_t n = counters[0] == 0u ? n_contrib[pid] : 0u;
+    out[pid] = n > 0u ? ((uint32_t)entries[ranges[(y / LG_TILE) * gx + x / LG_TILE].x + n - 1u] & gid_mask) : 0xFFFFFFFFu;
+}
+extern "C" int lg_debug_last_contributor(const lg_view* v, int32_t N, const void* geom_p, const void* bin_p, const void* img_p, int64_t R,
+                                         uint32_t* out_ids, void* stream_p)
+{
+    if (!v || N <= 0 || !geom_p || !bin_p || !img_p || !out_ids || v->image_width <= 0 || v->image_height <= 0)
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_debug_last_contributor: missing buffer");
+    const int W = v->image_width, H = v->image_height, gx = (W + LG_TILE - 1) / LG_TILE;
+    GeomView geo = carve_geom(const_cast<void*>(geom_p), N);
+    ImgView img = carve_img(const_cast<void*>(img_p), W, H);
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, lg_segment_of(v));
+    const int gid_bits = bits_for((uint32_t)(N > 1 ? N : 2));
+    const uint32_t gid_mask = gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << gid_bits) - 1u);
+    const size_t P = (size_t)W * H;
+    lg_debug_last_contributor_kernel<<<(unsigned)((P + 255) / 256), 256, 0, (hipStream_t)stream_p>>>(W, H, gx, bin.ranges, bin.entries, gid_mask, img.n_contrib,
+                                                                                                  geo.counters, out_ids);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_last_contributor launch", e);
+    return LG_OK;
+}
+
 // diagnostics: the K4 radix sort on its own (stand-alone histogram pass + onesweep passes)
 extern "C" size_t lg_debug_sort_temp_bytes(int64_t n) { return n < 0 ? 0 : lg_sort_layout((size_t)n).total; }
 extern "C" int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, int32_t begin_bit, int32_t end_bit, void* temp,

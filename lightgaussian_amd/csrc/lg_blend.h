@@ -98,7 +98,13 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
+#ifdef LG_K6_TWO_CMP
     const bool contrib = ok && !sat;
+#else
+    // (ok && !sat) written as an exclusive-or of the two lane masks: hipcc evaluated `!sat` with a second v_cmp (ngt) next to the
+    // one for `sat` -- compares cost 1.7x an fma on gfx950 -- where one s_xor of the masks does
+    const bool contrib = ok != sat;
+#endif
     // one select on the weight instead of three on the colours: fmaf(rgb, 0, C) == C bit for bit (finite rgb)
     if (COLOR) {   // significance-only passes (LG_FLAG_SKIP_COLOR) carry no colour at all
         const float w = contrib ? alpha * T : 0.0f;
@@ -182,23 +188,25 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 // footprint box (x +- hx, y +- hy) vs this wave's 8x8 pixel block; hx = inf when culling is off
                 hit = lg_block_hit(r0, r1, r2, lg_reach(r0, r1, r2), bx0, by0);
             }
-            uint64_t mask = __ballot(hit);
+            const uint64_t mask = __ballot(hit);
             if (mask == 0) continue;
             if (hit) {
                 const uint32_t pos = prefix_popc(mask);
+                // the queue copy carries the entry's contributor index (1-based position in the tile's list) where the record has
+                // the box half-extent hx, which nothing reads after the block test: it arrives with the colour in ONE ds_read_b64,
+                // and the walk below is a counted loop (was: pop the lowest set bit of the hit mask per step -- s_ff1, two 64-bit
+                // scalar ops, an add and a v_mov per hit)
+                r2.y = __uint_as_float(idx - range.x + 1u);
                 q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
             }
             __builtin_amdgcn_wave_barrier();
             int mycnt = 0;
             float myf = 0.0f;
-            uint32_t j = 0;
-            const uint32_t rel = base - range.x + 1; // contributor index of source lane 0
-            while (mask) {
-                const uint32_t src = (uint32_t)__builtin_ctzll(mask);
-                mask &= mask - 1;
+            const uint32_t nhit = (uint32_t)__popcll(mask);
+            for (uint32_t j = 0; j < nhit; j++) {
                 const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
                 float alpha = 0.0f, Tprev = T, w = 0.0f;
-                const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, rel + src, alpha, w) ? 1 : 0;
+                const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w) ? 1 : 0;
                 if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
                 if (COUNT) {
                     const uint64_t cm = __ballot(res == 1);
@@ -210,11 +218,10 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                         if (lane == j) myf = tot;
                     }
                 }
-                j++;
             }
             if (COUNT) {
                 // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
-                if (lane < j && mycnt > 0) {
+                if (lane < nhit && mycnt > 0) {
                     const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
                     atomicAdd(&count[id], mycnt);
                     if (FSCORE) atomicAdd(&fscore[id], myf);
@@ -610,12 +617,8 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
     return false;
 }
 
-// Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
-// the whole sequence and invalid lanes are neutralised by zeroing t and the colour weight and by
-// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
-// early-out when no lane of the 8x8 block takes the entry -- `if (__ballot(ok) == 0) return` -- was measured: 0.946 vs
-// 0.927 ms; blocks that pass the box test almost always have a contributing pixel.)
-__device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
+#ifdef LG_K7_VEC_COLOUR   // A/B switch (round 3): the colour recurrence as a 3-vector per pixel, as shipped in round 2
+__device__ __forceinline__ bool bwd_pair_fast_vec(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
                                               float& T, float Tfb, float g0, float g1, float g2, float& a0, float& a1,
                                               float& a2, float (&p)[9])
 {
@@ -653,9 +656,56 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
     p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
     return ok;
 }
+#endif
 
+// Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
+// the whole sequence and invalid lanes are neutralised by zeroing t and the colour weight and by
+// selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
+// early-out when no lane of the 8x8 block takes the entry -- `if (__ballot(ok) == 0) return` -- was measured: 0.946 vs
+// 0.927 ms; blocks that pass the box test almost always have a contributing pixel.)
+__device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
+                                              float& T, float Tfb, float g0, float g1, float g2, float& S, float (&p)[9])
+{
+#pragma clang fp contract(fast)
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
+    const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
+    const float op = b.y;
+    const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
+    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (S + 0 * d = S)
+    // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
+    const float am = ok ? alpha : 0.0f;
+    const float inv = __builtin_amdgcn_rcpf(1.0f - am);
+    const float Tn = T * inv;
+    // S = (colour accumulated behind this entry) . dL/dC of this pixel, carried as ONE scalar (round 3): the published
+    // recurrence a <- a + alpha (c - a) is linear, so its projection on g obeys S <- S + alpha (c.g - S), and dL/dalpha only
+    // ever needs (c - a) . g = c.g - S.  5 instructions (c.g: mul + 2 fma; d; S update) where the vector form took 9 (three
+    // differences, their dot product, three updates), and one state register per pixel instead of three.
+    const float d = (b.z * g0 + b.w * g1 + c.x * g2) - S;
+    const float dL_dalpha = d * Tn - Tfb * inv;          // Tfb = T_final * (bg . dL/dC), per pixel
+    const float t = ok ? G * dL_dalpha : 0.0f;
+    // no select on T: on invalid lanes am = 0, and v_rcp_f32(1.0f) is exactly 1.0f on gfx950, so Tn == T bit for bit there
+    // (measured: gradients bit-identical to the version with `T = ok ? Tn : T`, K7 1.2 % faster)
+    T = Tn;
+    S = am * d + S;
+    const float dch = am * Tn;
+    const float tdx = t * dx, tdy = t * dy;
+    p[0] += tdx;
+    p[1] += tdy;
+    p[2] += tdx * dx;
+    p[3] += tdx * dy;
+    p[4] += tdy * dy;
+    p[5] += t;
+    p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
+    return ok;
+}
+
+#ifndef LG_K7_WAVES
+#define LG_K7_WAVES 5      // waves per SIMD the register allocation of lg_blend_bwd aims for (84 VGPRs as written: 5)
+#endif
 template <bool EXACT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LG_K7_WAVES, 8)))
 lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const uint4* __restrict__ tinfo, const float4* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -678,6 +728,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
 
     float pxf[4], pyf[4], T[4], Tfb[4], g0[4], g1[4], g2[4], a0[4], a1[4], a2[4], la[4], lc0[4], lc1[4], lc2[4];
+    float Sd[4];            // hardware-exp variant: (colour behind) . dL/dC per pixel, instead of a0..a2 (bwd_pair_fast)
     uint32_t last[4];
     bool inside4[4];
     uint32_t wmax = 0;
@@ -694,7 +745,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
         g1[s] = inside ? dL_dpix[HW + pid] : 0.0f;
         g2[s] = inside ? dL_dpix[2 * HW + pid] : 0.0f;
         Tfb[s] = T[s] * (bgr * g0[s] + bgg * g1[s] + bgb * g2[s]);   // T_final * (bg . dL/dC): the background term of dL/dalpha
-        a0[s] = a1[s] = a2[s] = la[s] = lc0[s] = lc1[s] = lc2[s] = 0.0f;
+        a0[s] = a1[s] = a2[s] = la[s] = lc0[s] = lc1[s] = lc2[s] = Sd[s] = 0.0f;
         wmax = max(wmax, last[s]);
     }
 #pragma unroll
@@ -724,6 +775,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                 const float inv = 1.0f / here.x;
                 T[s] = here.x;
                 a0[s] = b0 * inv; a1[s] = b1 * inv; a2[s] = b2 * inv;
+                Sd[s] = (b0 * g0[s] + b1 * g1[s] + b2 * g2[s]) * inv;
             }
         }
     }
@@ -778,8 +830,11 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                                     contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s],
                                                               la[s], lc0[s], lc1[s], lc2[s], p);
                             } else {
-                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s],
-                                                         a1[s], a2[s], p);
+#ifdef LG_K7_VEC_COLOUR
+                                contrib |= bwd_pair_fast_vec(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s], p);
+#else
+                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
+#endif
                             }
                         }
                     }

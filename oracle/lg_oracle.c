@@ -301,6 +301,22 @@ void lgo_free(lgo_ctx *ctx)
 
 uint64_t lgo_num_rendered(const lgo_ctx *ctx) { return ctx ? ctx->R : 0; }
 
+/* Gaussian id of the last contributor of every pixel (0xFFFFFFFF: none), from the per-pixel contributor index the forward
+ * left: n_contrib itself is a position in THIS implementation's tile list (the oracle enumerates the reference's full
+ * rectangles, the HIP path culls instances that cannot contribute), the id it points at is what two implementations share. */
+void lgo_last_contributor_ids(const lgo_ctx *ctx, const int *n_contrib, uint32_t *out_ids)
+{
+    const int W = ctx->W, H = ctx->H, gx = ctx->gx;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t pid = (size_t)y * W + x;
+            const int t = (y / TILE) * gx + (x / TILE);
+            const int n = n_contrib[pid];
+            out_ids[pid] = n > 0 ? ctx->point_list[ctx->range_lo[t] + (uint32_t)n - 1u] : 0xFFFFFFFFu;
+        }
+}
+
 /* per-view score from an integer hit count: c sequential additions of w starting from 0 in
  * the accumulator precision -- exactly what c atomicAdd(score, w) calls produce (all addends
  * equal => order independent).  SURVEY.md section 8a-note. */

@@ -46,6 +46,7 @@ SCENES = [dict(N=3000, W=200, H=120, scale=0.05, opm=1.0, seed=2), dict(N=800, W
 def test_segmented_backward_equals_the_unsegmented_one(sc, S):
     kw = _scene(**sc)
     gimg = np.random.RandomState(3).randn(3, sc["H"], sc["W"]).astype(np.float32)
+    rasterizer.set_option("long_tiles", "serial")               # this test is about the BACKWARD's segments: one forward walk for both
     rasterizer.set_option("segment_length", 1 << 20)            # effectively unsegmented
     a = gpu_common.hip_forward_backward(kw, grad_image=gimg)
     rasterizer.set_option("segment_length", S)
