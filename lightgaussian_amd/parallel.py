@@ -52,6 +52,59 @@ def allreduce_gradients(params, group=None, average=True, bucket_bytes=512 << 20
     return len(works)
 
 
+def _pack_bits(mask):
+    """bool [N] -> int32 [ceil(N / 32)] bit words (device-side, no sync)."""
+    n = mask.shape[0]
+    pad = (-n) % 32
+    m = torch.nn.functional.pad(mask.to(torch.int32), (0, pad)).view(-1, 32)
+    w = (m << torch.arange(32, device=mask.device, dtype=torch.int32)).sum(dim=1, dtype=torch.int64)     # bit 31 set => > int32 max
+    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
+
+
+def _unpack_bits(words, n):
+    bits = (words.view(-1, 1) >> torch.arange(32, device=words.device, dtype=torch.int32)) & 1
+    return bits.reshape(-1)[:n].bool()
+
+
+def allreduce_gradients_visible(params, visible, group=None, average=True):
+    """Gradient all-reduce of only the rows that can be non-zero (r2 verdict item 9).  A Gaussian that no camera of the step saw
+    (radii == 0 on every rank: a third of the scene per view at C3 / C5) has an exactly zero gradient row in every tensor on
+    every rank; exchanging those rows moves zeros.  Two collectives instead of one dense one:
+      1. the per-rank visibility bitmaps (N / 8 bytes: 0.75 MB at 6 M Gaussians), all-reduced with bitwise OR;
+      2. ONE sum all-reduce of the union's rows of all parameters, packed into one flat buffer (few, large collectives for
+         point-to-point xGMI); the reduced rows are scattered back, every other row stays what it is -- zero.
+    At C5 (6 M Gaussians, 236 B of gradients each, ~2/3 visible per view) this cuts 1.4 GB per step to ~0.9 GB on 8 ranks with
+    different cameras -- less when ranks look at the same part of the scene.  The result equals allreduce_gradients(params) up to
+    the order in which the ring sums the ranks' contributions (identical at world size 2).
+    params: tensors [N, ...] with .grad; visible: bool [N] = visibility_filter of this rank's render(s) of the step (union over a
+    camera batch).  Costs one host sync (the size of the union).  Returns (rows exchanged, N)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, int(visible.shape[0])
+    world = dist.get_world_size(group)
+    N = int(visible.shape[0])
+    if world == 1:
+        return 0, N
+    grads = [p.grad for p in params if p.grad is not None]
+    if any(g.shape[0] != N for g in grads):
+        raise ValueError("allreduce_gradients_visible: every gradient must have one row per Gaussian")
+    words = _pack_bits(visible.reshape(-1).bool())
+    dist.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
+    idx = torch.nonzero(_unpack_bits(words, N)).reshape(-1)             # the one host sync: sizes the packed buffer
+    k = int(idx.shape[0])
+    if k == 0 or not grads:
+        return 0, N
+    flat = torch.cat([g.view(N, -1).index_select(0, idx).reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat.div_(world)
+    off = 0
+    for g in grads:
+        w = g[0].numel()
+        g.view(N, -1).index_copy_(0, idx, flat[off:off + k * w].view(k, w))
+        off += k * w
+    return k, N
+
+
 class OverlappedGradAllReduce:
     """Gradient all-reduce overlapped with the backward (the data-parallel step of distill_train.py:124-166 /
     prune_finetune.py with one camera per rank).  Inside the context every rasterizer backward runs its per-Gaussian stage

@@ -88,3 +88,40 @@ def test_overlapped_allreduce_of_gradient_ranges(tmp_path):
         mean = ((per_rank[0][k] + per_rank[1][k]) / 2).numpy()
         for o in outs:
             assert np.allclose(o[k], mean, rtol=1e-6, atol=1e-7), k
+
+
+def _visible_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(300 + rank)
+        N = 1003
+        vis = torch.rand(N, generator=g) < 0.4                      # what this rank's camera saw
+        shapes = [(N, 3), (N, 1, 3), (N, 8, 3), (N, 1), (N, 4)]
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g) * vis.view(-1, *([1] * (p.dim() - 1)))   # zero rows where nothing was seen
+        dense = [p.grad.clone() for p in params]
+        for d in dense:
+            dist.all_reduce(d); d.div_(world)
+        k, n = parallel.allreduce_gradients_visible(params, vis)
+        union = vis.clone().to(torch.int32)
+        dist.all_reduce(union)
+        assert n == N and k == int((union > 0).sum())
+        for p, d in zip(params, dense):
+            assert torch.equal(p.grad, d)                            # world 2: a + b == b + a, bit for bit
+        # nothing visible anywhere: no rows, gradients untouched
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        assert parallel.allreduce_gradients_visible(params, torch.zeros(N, dtype=torch.bool)) == (0, N)
+        np.savez(os.path.join(out_dir, f"v{rank}.npz"), k=k)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_visible_rows_allreduce_equals_the_dense_one(tmp_path):
+    """allreduce_gradients_visible: OR of the visibility bitmaps, then one sum all-reduce of the union's rows only -- same
+    gradients as the dense all-reduce (rows nobody saw are exactly zero everywhere)."""
+    mp.spawn(_visible_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ks = [int(np.load(tmp_path / f"v{r}.npz")["k"]) for r in range(2)]
+    assert ks[0] == ks[1] and 500 < ks[0] < 800                     # 1 - 0.6^2 = 64 % of 1003 rows

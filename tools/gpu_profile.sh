@@ -3,7 +3,7 @@
 #   pass 1  rocprofv3 --kernel-trace --stats            -> per-kernel launch time
 #   pass 2/3 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes: TCC slots)  -> HBM traffic
 #   pass 3-7 SQ counter sets                             -> instruction counts / busy cycles
-# summarised by tools/profile_summary.py into gpurun_out/r02_profile_<mode>.json (copy to profiles/).
+# summarised by tools/profile_summary.py into gpurun_out/r03_profile_<mode>.json (copy to profiles/).
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 MODE=${1:-fwdbwd}; shift
@@ -20,7 +20,7 @@ S=$(find gpurun_out/prof_$MODE -name '*kernel_stats.csv' | head -1)
 C() { find gpurun_out/pmc_${MODE}_$1 -name '*counter_collection.csv' | head -1; }
 python tools/profile_summary.py --mode $MODE --stats $S --fetch $(C 1) --write $(C 2) --sq $(C 3) $(C 4) $(C 5) $(C 6) $(C 7) \
   --command "rocprofv3 [--kernel-trace --stats | --pmc <set>] -- python bench.py --mode $MODE --no-cpu-baseline --no-roofline --no-literal $* (tools/gpu_profile.sh)" \
-  > gpurun_out/r02_profile_$MODE.json
-cp $S gpurun_out/r02_${MODE}_kernel_stats.csv
-head -c 1200 gpurun_out/r02_profile_$MODE.json; echo
+  > gpurun_out/r03_profile_$MODE.json
+cp $S gpurun_out/r03_${MODE}_kernel_stats.csv
+head -c 1200 gpurun_out/r03_profile_$MODE.json; echo
 find gpurun_out -name '*kernel_trace.csv' -size +5M -delete; find gpurun_out -name '*.db' -size +5M -delete
