@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count", "distill"], default="fwdbwd")
     ap.add_argument("--no-distill-overlap", action="store_true", help="--mode distill: teacher and student forwards in sequence on one stream")
+    ap.add_argument("--dense-allreduce", action="store_true", help="--mode distill, N > 1: all-reduce the dense gradient tensors (1.4 GB at C5) instead of "
+                    "only the rows some rank's camera saw (parallel.allreduce_gradients_visible, the default)")
     ap.add_argument("--n-gaussians", type=int, default=3_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -277,6 +279,8 @@ def main():
             return loss_utils.l1_dssim_loss(image, gt, 0.2)[0]
         return 0.8 * (image - gt).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt))
 
+    comm_events, comm_rows = ([] if (args.mode == "distill" and world > 1) else None), []
+
     def step(i, collectives=True):
         k = my_views[i % len(my_views)]
         if args.mode == "fwdbwd":
@@ -294,9 +298,18 @@ def main():
             for p in sparams:
                 p.grad = None
             # teacher forward on a side stream next to the student's forward (parallel.distill_step; --no-distill-overlap: in sequence)
-            parallel.distill_step(pc, student, cams[k], pipe, bg, loss_fn=lambda a, b: (a - b).abs().mean(), overlap=not args.no_distill_overlap)
-            if collectives:   # the rank-0-only measurement legs below must not enter a collective
-                parallel.allreduce_gradients(sparams)
+            _l, _t, spkg = parallel.distill_step(pc, student, cams[k], pipe, bg, loss_fn=lambda a, b: (a - b).abs().mean(), overlap=not args.no_distill_overlap)
+            if collectives and world > 1:   # the rank-0-only measurement legs below must not enter a collective
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if comm_events is not None else None
+                if ev:
+                    ev[0].record()
+                if args.dense_allreduce:
+                    parallel.allreduce_gradients(sparams)
+                else:
+                    comm_rows.append(parallel.allreduce_gradients_visible(sparams, spkg["visibility_filter"])[0])
+                if ev:
+                    ev[1].record()
+                    comm_events.append(ev)
         else:
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
@@ -464,6 +477,19 @@ def main():
         extra["timed_steps"] = extra["steady_state"]["steps"]
         extra["timed_seconds"] = extra["steady_state"]["seconds"]
 
+    if comm_events:
+        # data-parallel distillation step: how much of it is the gradient exchange (hipEvents around the collectives of the last
+        # timed steps on this rank's stream; no multi-GPU timing existed before round 3's first driver run)
+        torch.cuda.synchronize()
+        tail = comm_events[-min(len(comm_events), args.steps):]
+        ar_ms = sum(a.elapsed_time(b) for a, b in tail) / len(tail)
+        extra["data_parallel"] = {"allreduce_ms": round(ar_ms, 4), "compute_ms": round(ms_per_step - ar_ms, 4),
+                                  "exchange": "dense tensors (allreduce_gradients)" if args.dense_allreduce else
+                                              "rows seen by any rank's camera (allreduce_gradients_visible: bitmap OR + one packed sum)",
+                                  "rows_exchanged_mean": (round(sum(comm_rows[-len(tail):]) / len(tail), 1) if comm_rows else None),
+                                  "rows_total": N, "bytes_per_row": 4 * (3 + 3 * ((max(args.sh_degree - 1, 0) + 1) ** 2) + 1 + 3 + 4),
+                                  "note": "allreduce_ms = hipEvent time around the gradient collectives of one step on rank 0 (includes waiting for the slowest rank); "
+                                          "compute_ms = ms_per_step - allreduce_ms"}
     result = None
     if rank == 0:
         stats = _lib.last_stats()

@@ -663,8 +663,8 @@ __device__ __forceinline__ bool bwd_pair_fast_vec(const float4& a, const float4&
 // selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
 // early-out when no lane of the 8x8 block takes the entry -- `if (__ballot(ok) == 0) return` -- was measured: 0.946 vs
 // 0.927 ms; blocks that pass the box test almost always have a contributing pixel.)
-__device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
-                                              float& T, float Tfb, float g0, float g1, float g2, float& S, float (&p)[9])
+__device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
+                                                  float& T, float Tfb, float g0, float g1, float g2, float& S, float (&p)[9])
 {
 #pragma clang fp contract(fast)
     const float dx = a.x - pxf, dy = a.y - pyf;
@@ -698,7 +698,9 @@ __device__ __forceinline__ bool bwd_pair_fast(const float4& a, const float4& b, 
     p[4] += tdy * dy;
     p[5] += t;
     p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
-    return ok;
+    // the lanes that contributed, as the lane mask the compare produced (a bool OR-ed over the sub-blocks and balloted afterwards
+    // cost a v_cndmask + v_cmp per entry to rebuild the mask the scalar unit already had)
+    return __ballot(ok);
 }
 
 #ifndef LG_K7_WAVES
@@ -819,27 +821,42 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                 const float4 a = q0[j], b = q1[j];
                 const float4 c = make_float4(q2[j], 0.0f, 0.0f, 0.0f);
                 const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
-                float p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                bool contrib = false;
-                {
+                float p[9];
+                uint64_t cmask = 0;                        // lanes for which the entry contributed in any sub-block (scalar)
+                if (EXACT) {
+#pragma unroll
+                    for (int v = 0; v < 9; v++) p[v] = 0.0f;
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
                         if (m & (1u << s)) {
-                            if (EXACT) {
-                                if (rel <= last[s])
-                                    contrib |= bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s],
-                                                              la[s], lc0[s], lc1[s], lc2[s], p);
-                            } else {
-#ifdef LG_K7_VEC_COLOUR
-                                contrib |= bwd_pair_fast_vec(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s], p);
-#else
-                                contrib |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
-#endif
-                            }
+                            bool cb = false;
+                            if (rel <= last[s])
+                                cb = bwd_pair<true>(a, b, c, pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s],
+                                                    la[s], lc0[s], lc1[s], lc2[s], p);
+                            cmask |= __ballot(cb);
                         }
                     }
+                } else {
+#ifdef LG_K7_VEC_COLOUR
+#pragma unroll
+                    for (int v = 0; v < 9; v++) p[v] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        if (m & (1u << s))
+                            cmask |= __ballot(bwd_pair_fast_vec(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s], p));
+#else
+                    // (round 3, measured and rejected: dispatching on the lowest hit sub-block so that it ASSIGNS the nine partial
+                    //  sums -- no zeroing: 9 v_mov per entry whenever sub-block 0 is not hit -- made the kernel 7 % SLOWER,
+                    //  0.695 -> 0.745 ms: ten copies of the pair step instead of four, 92 VGPRs)
+#pragma unroll
+                    for (int v = 0; v < 9; v++) p[v] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        if (m & (1u << s))
+                            cmask |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
+#endif
                 }
-                if (__ballot(contrib) == 0) continue;
+                if (cmask == 0) continue;
 #ifdef LG_K7_DPP_REDUCE
                 wave_reduce9_to_lds(p, stage + j * 9, lane);
 #else
