@@ -93,14 +93,16 @@ def test_backward_parity(case):
         if CASES.index(case) in WELL_CONDITIONED:
             assert ex32 <= 1.0 and ex <= 1.0, f"grad {name}: element-wise bound missed on a well-conditioned scene ({ex:.2f}x, fp32 oracle {ex32:.2f}x)"
         # every scene, the saturating / screen-filling ones included (r2 verdict: there the tensor-level bound is 8-1600x the
-        # element bound, "no test would notice a 100x regression"): on the ENTRIES where float32 is trustworthy -- the float32
-        # oracle within a quarter of the element bound of the float64 one -- the HIP path meets the element bound itself
+        # element bound, "no test would notice a 100x regression"): the DISTRIBUTION of the HIP path's element errors (in units of
+        # the element bound, against the float64 oracle) must not be worse than 3x that of the float32 oracle -- at the median, at
+        # the 99th and at the 99.9th percentile (floor: a tenth of the bound).  A single entry proves nothing on an ill-conditioned
+        # scene (where float32 lands is luck); a broad loss of accuracy moves the quantiles.
         r64 = np.asarray(r, np.float64).reshape(-1); a64 = np.asarray(g, np.float64).reshape(-1); o32 = np.asarray(g32[name], np.float64).reshape(-1)
         bound = 1e-4 * np.abs(r64) + 2e-5 * (np.abs(r64).max() + 1e-300)
-        well = np.abs(o32 - r64) <= 0.25 * bound
-        if well.any():
-            worst = float((np.abs(a64 - r64)[well] / bound[well]).max())
-            assert worst <= 1.0, f"grad {name}: {worst:.2f}x the element bound on an entry where the float32 oracle is within 0.25x ({well.mean():.3f} of the entries qualify)"
+        rh, ro = np.abs(a64 - r64) / bound, np.abs(o32 - r64) / bound
+        for q in (0.5, 0.99, 0.999):
+            qh, qo = float(np.quantile(rh, q)), float(np.quantile(ro, q))
+            assert qh <= max(0.1, 3.0 * qo), f"grad {name}: {q:.3f}-quantile of the element error is {qh:.3f}x the bound (float32 oracle: {qo:.3f}x)"
 
 
 def test_render_equals_count_render_image():

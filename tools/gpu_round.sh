@@ -1,17 +1,36 @@
 #!/bin/bash
-# GPU box: full -m gpu suite, smoke(), then short benches of the given modes (fwdbwd fwd count fused)
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -30 > gpurun_out/pytest_gpu.log; tail -8 gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
-for mode in "$@"; do
-  EXTRA=""; if [ "$mode" = "nofuse" ]; then mode=fwdbwd; EXTRA="--no-fuse"; fi
-  timeout 300 python bench.py --steps 50 --warmup 10 --mode $mode $EXTRA --no-cpu-baseline > gpurun_out/bench_$mode$EXTRA.log 2>&1; tail -1 gpurun_out/bench_$mode$EXTRA.log | python -c "
+# One round's measurement run on a GPU box: the whole -m gpu suite, smoke, the bench modes / configs quoted in DESIGN.md 11, the
+# rocprofv3 evidence (tools/gpu_profile.sh -> gpurun_out/<round>_profile_<mode>.json + kernel stats CSV; copy them to profiles/).
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh'
+mkdir -p gpurun_out; export TMPDIR=/tmp
+run() { timeout -s KILL 600 python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
 import sys, json
-l=sys.stdin.read().strip()
-try:
-    d=json.loads(l); print(d['metric'], d['value'], 'ms/step', d['ms_per_step'], d.get('kernels_ms'))
-except Exception as e: print('RAW', l[-2000:])
-"
-done
-echo "PYTEST: $(grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -1)"; echo "SMOKE: $(tail -1 gpurun_out/smoke.log)"
+d=json.loads(sys.stdin.read().strip()); c=d['config']; print('$*', '->', d['value'], 'views/s', d['ms_per_step'], 'ms', 'burst', (d.get('contract_region') or {}).get('views_per_s'), 'V', c['visible_gaussians'], 'R', c['tile_instances'], d.get('kernels_ms'), 'batch3', (d.get('camera_batch_3') or {}), (d.get('significance_pass') or {}), (d.get('literal_getter_pattern') or {}))" | cut -c1-1800; }
+timeout -s KILL 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15 > gpurun_out/round_pytest.log; grep -E "passed|failed" gpurun_out/round_pytest.log | tail -1; grep -E "^FAILED|^E  " gpurun_out/round_pytest.log | cut -c1-300 | head
+timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+( time timeout -s KILL 900 python bench.py ) > gpurun_out/round_bench_default.log 2>&1; tail -5 gpurun_out/round_bench_default.log | cut -c1-7000
+run --n-gaussians 1000000 --mode fwd --steps 100 --no-literal
+run --n-gaussians 3000000 --mode fwd --steps 100 --no-literal
+run --n-gaussians 3000000 --mode count --steps 100
+run --n-gaussians 3000000 --mode count --steps 100 --scene heavy
+run --n-gaussians 3000000 --mode count --steps 100 --scale 0.0045
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --no-fuse
+run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 100 --sync-free off --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 100 --long-tiles serial --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 30 --loss l1_dssim_torch --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwdbwd --steps 50 --sh-degree 2 --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwd --steps 50 --sh-degree 3 --no-literal
+run --n-gaussians 6000000 --width 1600 --height 1060 --mode distill --steps 30 --sh-degree 3
+run --n-gaussians 3000000 --mode fwdbwd --steps 30 --scale 0.012 --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scene heavy --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scene heavy --long-tiles serial --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scale 0.0045 --no-literal
+run --n-gaussians 6000000 --width 3840 --height 2160 --mode fwdbwd --steps 20 --no-literal
+timeout -s KILL 300 python tools/vq_bench.py 2>&1 | tail -4
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
+bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
+bash tools/gpu_profile.sh count 2>&1 | tail -3 | cut -c1-200
