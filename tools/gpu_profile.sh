@@ -23,4 +23,5 @@ python tools/profile_summary.py --mode $MODE --stats $S --fetch $(C 1) --write $
   > gpurun_out/r03_profile_$MODE.json
 cp $S gpurun_out/r03_${MODE}_kernel_stats.csv
 head -c 1200 gpurun_out/r03_profile_$MODE.json; echo
-find gpurun_out -name '*kernel_trace.csv' -size +5M -delete; find gpurun_out -name '*.db' -size +5M -delete
+# the summary and the stats CSV are what travels back (gpurun merges at most 64 MiB); the raw rocprofv3 output stays on the box
+rm -rf gpurun_out/prof_$MODE gpurun_out/pmc_${MODE}_[0-9]*
