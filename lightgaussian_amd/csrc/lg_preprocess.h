@@ -66,7 +66,11 @@ __device__ __forceinline__ float lg_sigmoid(float x) { return 1.0f / (1.0f + exp
 
 // 92 VGPRs -> 5 waves/SIMD.  Forcing 6 or 8 (amdgpu_waves_per_eu) spills 43 / 71 registers: measured 0.22 -> 0.28 / 0.45 ms.
 template <bool RAW, bool DIRECT>
+#ifdef LG_K1_WAVES
+__global__ void __launch_bounds__(LG_PP) __attribute__((amdgpu_waves_per_eu(LG_K1_WAVES, 8)))
+#else
 __global__ void __launch_bounds__(LG_PP)
+#endif
 lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int skip_color,
               const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
               const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
@@ -221,7 +225,13 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 // 151 VGPRs -> 3 waves/SIMD.  Forcing 4 (amdgpu_waves_per_eu, 12 spilled registers) was measured: 0.37 -> 0.50 ms.
 // Reading the SH rows directly per lane as K1 does (only the visible rows, no input staging) was measured: 0.380 vs 0.380 ms.
 template <bool RAW>
+// 155 VGPRs -> 3 waves/SIMD.  Forcing 4 (-DLG_K9_WAVES=4: 128 VGPRs, 76 B/lane of scratch) was measured in round 3:
+// 0.384 -> 0.594 ms -- the spills cost more than the fourth wave hides; 5 is not reachable (the compiler gives up at 157).
+#ifdef LG_K9_WAVES
+__global__ void __launch_bounds__(LG_PP) __attribute__((amdgpu_waves_per_eu(LG_K9_WAVES, 8)))
+#else
 __global__ void __launch_bounds__(LG_PP)
+#endif
 lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfovx, float tanfovy, float mod,
                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
                   const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest,
