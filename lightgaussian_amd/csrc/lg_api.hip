@@ -183,6 +183,15 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream));
         }
     }
+    // bounded forward: K1 also clears the sort's histograms / tickets / states (the buffer and the key layout are known already)
+    uint32_t* k1_clear = nullptr;
+    uint32_t k1_nclear = 0;
+    if (bounded && N > 0 && cap > 0) {
+        const LgSortLayout SL0 = lg_sort_layout((size_t)cap);
+        const int sb = kp.gid_bits + kp.drop, se = kp.gid_bits + kp.stored() + kp.tile_bits;
+        k1_clear = (uint32_t*)bin.sort_temp;
+        k1_nclear = (uint32_t)(lg_sort_clear_bytes(SL0, (unsigned)((se - sb + 7) / 8)) / 4);
+    }
     if (N > 0) {
         {
             ProfScope ps(prof, "preprocess", stream);
@@ -190,7 +199,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     lg_preprocess<RAWP, DIR><<<nblk, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
-                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score)
+                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score, \
+                                                                      k1_clear, k1_nclear)
             // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
             const bool direct = !(v->flags & LG_FLAG_K1_LDS);
             const bool raw = v->flags & LG_FLAG_RAW_PARAMS;
@@ -256,8 +266,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const int sort_begin = kp.gid_bits + kp.drop, sort_end = kp.gid_bits + kp.stored() + kp.tile_bits;
     if (cap > 0 && N > 0) {
         const LgSortLayout SL = lg_sort_layout((size_t)cap);
-        // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass
-        HIP_TRY(lg_zero_async(bin.sort_temp, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
+        // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass (exact forward: the
+        // buffer was allocated a moment ago; the bounded forward's K1 did it already)
+        if (!k1_clear) HIP_TRY(lg_zero_async(bin.sort_temp, lg_sort_clear_bytes(SL, (unsigned)((sort_end - sort_begin + 7) / 8)), stream));
         uint32_t* hist = (uint32_t*)((char*)bin.sort_temp + SL.hist_off);
         {
             ProfScope ps(prof, "duplicate", stream);

@@ -77,7 +77,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
               const float* __restrict__ colors_precomp,
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii, int32_t* __restrict__ zero_count,
-              float* __restrict__ zero_score)
+              float* __restrict__ zero_score, uint32_t* __restrict__ clear_words, uint32_t n_clear)
 {
     // DIRECT (default): every visible lane reads its own SH row with dwordx4 loads (read_row_direct) and no LDS is
     // allocated for SH (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3).  The LDS-staged
@@ -88,6 +88,10 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     const uint32_t lane = threadIdx.x;
     const int i0 = blockIdx.x * LG_PP;
     const int i = i0 + (int)lane;
+    // capacity-bounded forward: the binning buffer exists before this kernel runs, so the clear of the radix sort's digit
+    // histograms / tickets / look-back states (~2.6 MB at C3) rides here, a few words per workgroup, instead of in a launch of
+    // its own (lg_zero_words: 4.7 us, the duration of an empty launch on MI355X)
+    for (uint32_t w = blockIdx.x * LG_PP + lane; w < n_clear; w += gridDim.x * LG_PP) clear_words[w] = 0u;
     float vm[16], pm[16], cp[3];
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = viewmatrix[k]; pm[k] = projmatrix[k]; }
