@@ -268,15 +268,20 @@ static int cmp_inst(const void *a, const void *b)
 }
 #endif
 
-static void sort_instances(inst_t *a, size_t n)
+static void sort_instances(inst_t *a, size_t n, uint64_t ntiles)
 {
 #ifdef LG_F64
+    (void)ntiles;
     qsort(a, n, sizeof(inst_t), cmp_inst);
 #else
-    /* key = tile<<32 | depth_bits.  3 passes over the low 48 bits (tile id < 65536). */
+    /* key = tile<<32 | depth_bits.  3 passes over the low 48 bits while tile ids fit 16 bits, 4 beyond (round 3: a
+     * 4112 x 4096 image has 65 792 tiles). */
+    const int passes = ntiles > 65536u ? 4 : 3;
+    inst_t *orig = a;
     inst_t *b = (inst_t *)malloc(n * sizeof(inst_t));
+    inst_t *tmp = b;
     size_t *hist = (size_t *)malloc(65536 * sizeof(size_t));
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < passes; pass++) {
         int sh = 16 * pass;
         memset(hist, 0, 65536 * sizeof(size_t));
         for (size_t i = 0; i < n; i++) hist[(a[i].key >> sh) & 0xFFFF]++;
@@ -285,9 +290,9 @@ static void sort_instances(inst_t *a, size_t n)
         for (size_t i = 0; i < n; i++) b[hist[(a[i].key >> sh) & 0xFFFF]++] = a[i];
         inst_t *t = a; a = b; b = t;
     }
-    /* 3 passes: result is in the buffer currently named 'a', which is the original 'b' */
-    memcpy(b, a, n * sizeof(inst_t)); /* copy back into caller's array (now named b) */
-    free(a);
+    /* the result is in the buffer currently named 'a': the temporary after an odd number of passes */
+    if (a != orig) memcpy(orig, a, n * sizeof(inst_t));
+    free(tmp);
     free(hist);
 #endif
 }
@@ -400,7 +405,7 @@ lgo_ctx *lgo_forward(int N, int M, int D, int W, int H, const real *bg, const re
                 o++;
             }
     }
-    sort_instances(inst, R);
+    sort_instances(inst, R, (uint64_t)gx * (uint64_t)gy);
     ctx->point_list = (uint32_t *)malloc((R ? R : 1) * sizeof(uint32_t));
     ctx->range_lo = (uint32_t *)calloc((size_t)gx * gy, sizeof(uint32_t));
     ctx->range_hi = (uint32_t *)calloc((size_t)gx * gy, sizeof(uint32_t));

@@ -203,3 +203,32 @@ def test_c2_one_million_gaussians_1080p_forward_is_bit_identical_to_the_oracle()
     assert np.array_equal(cnt["gaussians_count"].cpu().numpy(), ref.count)
     assert np.array_equal(cnt["important_score"].cpu().numpy().view(np.uint32), ref.score.view(np.uint32))
     assert np.array_equal(cnt["render"].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+
+
+def test_a_key_that_really_exceeds_64_bits_renders_like_the_oracle():
+    """tile | depth | id beyond 64 bits without the cross-check switch: 1.1 M Gaussians (21 id bits) on 4112 x 4096 pixels (257 x 256
+    = 65 792 tiles: 17 bits).  The exact forward lays the depth out from the view's own maximum (26 bits here: 64 in all, it fits);
+    the capacity-bounded forward -- the default from the second view of a shape on -- from the camera's zfar (27 bits: 65), so the
+    lowest depth bit is left out of the stored key and lg_tile_ranges completes the order from the binning record.  Both must
+    equal the oracle bit for bit (r2: this shape fell back to a hipCUB pair sort and had no bounded form at all)."""
+    from lightgaussian_amd import rasterizer
+    from lightgaussian_amd.gaussian_renderer import count_render
+    dev = torch.device(DEV)
+    N, W, H = 1_100_000, 4112, 4096
+    pc = syn.make_gaussians(N, log_scale_mean=math.log(0.006)).to(dev)
+    cam = syn.orbit_camera(5, 200, W, H)
+    camd, bg, pipe = cam.to(dev), torch.zeros(3, device=dev), syn.PipelineParams()
+    ref = oracle.forward(count=True, **_oracle_kw(_activated_on_device(pc), cam, W, H, 3, np.zeros(3)))
+    key = (dev.index, N, W, H)
+    with rasterizer._CAP_LOCK:
+        rasterizer._CAPACITY.pop(key, None)
+    with torch.no_grad(), rasterizer.options(sync_free="validated"):
+        first = count_render(camd, pc, pipe, bg)            # exact forward (learns the capacity of this shape)
+        assert rasterizer._CAPACITY.get(key, 0) > 0
+        second = count_render(camd, pc, pipe, bg)           # bounded forward: 17 + 27 + 21 = 65 key bits
+    for out in (first, second):
+        assert np.array_equal(out["radii"].cpu().numpy(), ref.radii)
+        assert np.array_equal(out["gaussians_count"].cpu().numpy(), ref.count)
+        assert np.array_equal(out["important_score"].cpu().numpy().view(np.uint32), ref.score.view(np.uint32))
+        assert np.array_equal(out["render"].cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+    assert int(ref.count.sum()) > 10_000_000

@@ -157,3 +157,23 @@ def test_argument_validation_like_reference():
     bad = dict(kw); bad["cov3D_precomp"] = np.zeros((1, 6), np.float32)
     with pytest.raises(ValueError):
         oracle.forward(**bad)
+
+
+def test_more_than_65536_tiles_sort_on_all_tile_bits():
+    """The float32 oracle's instance sort is an LSD radix over 16-bit digits of tile<<32 | depth bits: 3 passes cover tile ids below
+    65 536, a 4112 x 4096 image has 65 792 (round 3: the oracle lost the 17th tile bit and the full-size test caught the ORACLE).
+    The float64 build sorts with qsort on (tile, depth, id): both must list the same Gaussians per pixel."""
+    W, H = 4112, 4096
+    g = syn.make_gaussians(300, seed=12, log_scale_mean=math.log(0.05), opacity_mean=0.0)
+    cam = syn.orbit_camera(2, 9, W, H)
+    kw = common.scene_kwargs(g, cam, W, H, deg=1, bg=(0.0, 0.0, 0.0))
+    a = oracle.forward(count=True, **kw)
+    b = oracle.forward(count=True, dtype=np.float64, **kw)
+    assert a.num_rendered == b.num_rendered and a.num_rendered > 300
+    assert np.array_equal(a.radii, b.radii)
+    assert np.abs(a.count.astype(np.int64) - b.count).max() <= max(2, int(2e-4 * b.count.max()))   # (float32 vs float64 thresholds)
+    assert np.array_equal(oracle.last_contributor_ids(a) != 0xFFFFFFFF, oracle.last_contributor_ids(b) != 0xFFFFFFFF) or \
+        np.mean((oracle.last_contributor_ids(a) != 0xFFFFFFFF) != (oracle.last_contributor_ids(b) != 0xFFFFFFFF)) < 1e-5
+    # (a pixel may differ by one alpha >= 1/255 decision between float32 and float64: <= 1/255 of a colour; a lost tile bit
+    #  moves whole tiles: thousands of pixels by O(0.1))
+    assert np.abs(a.color.astype(np.float64) - b.color).max() < 5e-3 and np.mean(np.abs(a.color - b.color) > 1e-5) < 1e-4
