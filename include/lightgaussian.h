@@ -153,8 +153,9 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  * the key layout on the host.  Nothing is read back and every launch is stream-ordered, so a view's forward + backward can
  * be issued from one host thread onto several streams, or captured into a hipGraph.
  *   status: device uint32[4], written on `stream` = { abort flags, prefiltered violation, largest depth bit pattern,
- *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth (bit 2, set later if ever:
- *           the radix sort's look-back gave up -- see lg_view_status).  When status[0] != 0 the
+ *           instance count R }.  abort bit 0: R > max_rendered; bit 1: a depth beyond max_depth; bit 2 (added to `status` by a
+ *           later kernel if it ever happens; `host_status` has left for the host by then -- see lg_view_status): the radix
+ *           sort's look-back gave up.  When status[0] != 0 the
  *           view was abandoned on the device (every later kernel returns at once; outputs undefined, gradients of a
  *           following lg_backward are zero) and the caller re-runs it through lg_forward -- the only host decision left.
  *   host_status: NULL, or HOST uint32[4] receiving the same four words before the call returns ("validated" mode).  The

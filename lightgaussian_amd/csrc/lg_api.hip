@@ -287,7 +287,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "tile_ranges", stream);
             const uint32_t rgrid = (uint32_t)((cap + 255) / 256);
             lg_tile_ranges<<<rgrid, 256, 0, stream>>>(geo.counters, kp.stored() + kp.gid_bits, kp.gid_bits, kp.gid_mask, kp.drop, kp.store_drop,
-                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges);
+                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges, bounded ? bounded->status : nullptr);
         }
         KCHECK("lg_tile_ranges");
     }

@@ -312,10 +312,17 @@ __device__ __forceinline__ void lg_wave_sort_run(uint32_t i, uint32_t e, int low
 
 __global__ void __launch_bounds__(256)
 lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, uint32_t gid_mask, int drop, int store_drop,
-               uint64_t* entries /* the sorted keys */, uint64_t* scratch, const uint4* __restrict__ tinfo, uint2* __restrict__ ranges)
+               uint64_t* entries /* the sorted keys */, uint64_t* scratch, const uint4* __restrict__ tinfo, uint2* __restrict__ ranges,
+               uint32_t* status /* lg_forward_bounded's status words, or NULL */)
 {
     __shared__ uint32_t s_cnt[4][256];
-    if (counters[0] != 0u) return;                 // view aborted (capacity-bounded forward, or the sort's look-back gave up)
+    if (counters[0] != 0u) {                       // view aborted (capacity-bounded forward, or the sort's look-back gave up)
+        // K2 handed the caller its copy of the abort word BEFORE the sort ran: an abort raised by the sort is added here
+        if (status && blockIdx.x == 0 && threadIdx.x == 0 && (counters[0] & LG_ABORT_SORT)) {
+            __hip_atomic_store(&status[0], counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     const uint32_t R = counters[3];                // the grid is sized for the capacity; the instance count lives on the device
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
