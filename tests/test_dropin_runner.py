@@ -113,3 +113,40 @@ def test_runner_command_line_sets_up_the_path_like_python_does(tmp_path, monkeyp
     assert rec["shim"].startswith(dropin_common.ROOT)
     bad = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--frobnicate", str(script)], capture_output=True, text=True, cwd=dropin_common.ROOT)
     assert bad.returncode != 0 and "unknown option" in bad.stderr
+
+
+def test_runner_rebinds_what_the_trainer_script_then_imports_by_name(tmp_path):
+    """The whole command-line flow on a reference-SHAPED checkout (a temporary directory with gaussian_renderer/, utils/loss_utils.py,
+    prune.py holding stand-ins): `python -m lightgaussian_amd.run trainer.py` patches first and runs the script afterwards, so the
+    trainer's own `from gaussian_renderer import render, count_render` / `from utils.loss_utils import l1_loss, ssim` /
+    `from prune import prune_list` bind this package's implementations; with --no-patch they bind the checkout's."""
+    import json
+    import subprocess
+    root = tmp_path / "LightGaussian"
+    (root / "gaussian_renderer").mkdir(parents=True)
+    (root / "utils").mkdir()
+    (root / "gaussian_renderer" / "__init__.py").write_text("def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):\n    return 'literal'\n"
+                                                            "def count_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):\n    return 'literal'\n")
+    (root / "utils" / "__init__.py").write_text("")
+    (root / "utils" / "loss_utils.py").write_text("def l1_loss(network_output, gt):\n    return 'literal'\ndef ssim(img1, img2, window_size=11, size_average=True):\n    return 'literal'\n")
+    (root / "prune.py").write_text("def prune_list(gaussians, scene, pipe, background):\n    return 'literal'\ndef calculate_v_imp_score(gaussians, imp_list, v_pow):\n    return 'literal'\n")
+    (root / "trainer.py").write_text(
+        "import json, sys\n"
+        "from utils.loss_utils import l1_loss, ssim\n"
+        "from gaussian_renderer import render, count_render\n"
+        "from prune import prune_list, calculate_v_imp_score\n"
+        "print(json.dumps({n: f.__module__ for n, f in dict(render=render, count_render=count_render, l1_loss=l1_loss, ssim=ssim,\n"
+        "                  prune_list=prune_list, calculate_v_imp_score=calculate_v_imp_score).items()}))\n")
+    def run(*flags):
+        out = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", *flags, str(root / "trainer.py")], capture_output=True, text=True,
+                             cwd=dropin_common.ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    patched = run()
+    assert patched["render"] == "lightgaussian_amd.gaussian_renderer" and patched["count_render"] == "lightgaussian_amd.gaussian_renderer"
+    assert patched["l1_loss"] == "lightgaussian_amd.loss_utils" and patched["ssim"] == "lightgaussian_amd.loss_utils"
+    # (the adapters live in run.py, which `python -m` executes under the name __main__)
+    assert patched["prune_list"] in ("lightgaussian_amd.run", "__main__") and patched["calculate_v_imp_score"] in ("lightgaussian_amd.run", "__main__")
+    literal = run("--no-patch")
+    assert literal == {"render": "gaussian_renderer", "count_render": "gaussian_renderer", "l1_loss": "utils.loss_utils", "ssim": "utils.loss_utils",
+                       "prune_list": "prune", "calculate_v_imp_score": "prune"}
