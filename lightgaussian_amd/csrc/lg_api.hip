@@ -307,13 +307,13 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode)
+                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived)
         const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode);
+            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived);
+            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived);
         }
         else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
         else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
@@ -325,9 +325,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         // without outlier lists: each launch is then one scalar load per workgroup)
         ProfScope ps(prof, "blend_fwd_long", stream);
         const uint32_t pgrid = (uint32_t)std::min<int64_t>((int64_t)ntiles + cap / S + 1, LG_PAR_GRID);
-        lg_blend_fwd_seg<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt, bin.ckpt_last);
-        lg_blend_fwd_scan<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, v->bg, out_color, img.final_T, img.n_contrib,
-                                                    bin.ckpt, bin.ckpt_last);
+        // (pass 2, the per-tile scan, runs inside the first launch: the workgroup that finishes a tile's last segment does it)
+        lg_blend_fwd_seg<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt, bin.ckpt_last,
+                                                   bin.par_arrived, v->bg, out_color, img.final_T, img.n_contrib);
         lg_blend_fwd_rewalk<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,
                                                       out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
         KCHECK("lg_blend_fwd_long");

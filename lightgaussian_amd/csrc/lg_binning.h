@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t lg_par_min(int long_mode, int S, uint32_t R,
 __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __restrict__ ranges, uint2* __restrict__ work,
                                                    uint32_t* __restrict__ meta, uint32_t* hist /* LDS [256] */,
                                                    uint32_t* base /* LDS [258] */, uint32_t tid, uint32_t nthreads,
-                                                   uint2* __restrict__ par_work, uint32_t par_min)
+                                                   uint2* __restrict__ par_work, uint32_t par_min, uint32_t* __restrict__ par_arrived)
 {
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) { base[256] = 0; base[257] = 0; }
@@ -424,6 +424,7 @@ __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __
         const uint2 r = ranges[t];
         const uint32_t n = r.y - r.x;
         const bool par = par_min != 0u && n > par_min;
+        if (par) par_arrived[t] = 0u;                             // arrival counter of the tile's segments (lg_blend_fwd_seg -> lg_scan_tile)
         uint32_t seg = 0;
         for (uint32_t lo = 0; lo < n; lo += (uint32_t)S, seg++) {
             work[atomicAdd(&base[255u - min(min((uint32_t)S, n - lo) >> 4, 255u)], 1u)] = make_uint2((uint32_t)t, seg);

@@ -126,7 +126,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
              uint2* __restrict__ work, uint32_t* __restrict__ meta, uint2* __restrict__ par_work, const uint32_t* __restrict__ counters,
-             int long_mode)
+             int long_mode, uint32_t* __restrict__ par_arrived)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
@@ -135,7 +135,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     if (blockIdx.x == (uint32_t)ntiles_pad) {
         // the one workgroup past the tiles: work list of the backward blend (lg_binning.h), overlapped with the blending
         uint32_t* scratch = reinterpret_cast<uint32_t*>(&q0[0][0]);
-        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, par_work, par_min);
+        lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, par_work, par_min, par_arrived);
         return;
     }
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
@@ -257,7 +257,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 // contributing entries, and the sequential result is T = prod P_s, colour = sum_s (prod_{s' < s} P_s') C_s.
 //   pass 1  lg_blend_fwd_seg : one workgroup per (long tile, segment) from the backward's work list walks its S entries with
 //           no termination test and leaves {P, C} and the last contributing list position per pixel (in the checkpoint slots);
-//   pass 2  lg_blend_fwd_scan: one workgroup per long tile, a thread per pixel: prefix products over the segments.  Pixels that
+//   pass 2  lg_scan_tile (run by the workgroup of pass 1 that finishes a tile's last segment), a thread per pixel: prefix products over the segments.  Pixels that
 //           never come near the termination threshold are finished (image, final T, n_contrib, the checkpoint records {T at
 //           the end of the segment, colour accumulated inside it} the backward starts from); a pixel whose transmittance would
 //           fall under the threshold INSIDE segment s* (T P_s* < 1e-4, with a margin) is parked at s*;
@@ -322,13 +322,66 @@ __device__ __forceinline__ void lg_walk_block(uint32_t list0, uint32_t lo, uint3
     }
 }
 
+// pass 2: per long tile, per pixel: prefix products over the segments.  A pixel whose transmittance never comes near the
+// termination threshold is finished here; one that would stop inside segment s* is parked -- {T before s*, colour so far} in
+// the checkpoint slot of s*, s* itself in the last-contributor word of slot 0 -- for lg_blend_fwd_rewalk.
+// Round 3: not a launch of its own any more.  The workgroup of lg_blend_fwd_seg that finishes the LAST segment of a tile (one
+// agent-scope arrival counter per tile, zeroed by the work-list workgroup of lg_blend_fwd) runs the tile's scan right away:
+// nothing waits (no spinning, no co-residency assumption), one launch less per view, and on scenes with outlier lists the
+// scans overlap the other tiles' segment walks.
+#define LG_NO_SEG 0xFFFFFFFFu
+__device__ __forceinline__ void lg_scan_tile(int W, int H, int gx, int S, int tile, const uint2 range, const float* __restrict__ bg,
+                                             float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                             float4* __restrict__ ckpt, uint32_t* __restrict__ ckpt_last, int wave, uint32_t lane)
+{
+    const uint32_t n = range.y - range.x;
+    const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+    const int tx = tile % gx, ty = tile / gx;
+    const int pxi = tx * LG_TILE + (wave & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (wave >> 1) * 8 + (int)(lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
+    float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0, sstar = LG_NO_SEG;
+    if (inside) {
+        for (uint32_t s = 0; s < nseg; s++) {
+            const float4 r = ck[(size_t)s * 256];
+            const uint32_t ll = cl[(size_t)s * 256];
+            const float Tend = T * r.x;
+            // would this pixel stop inside the segment?  (T P_s < 1e-4 up to the rounding of the regrouped product: the margin
+            // only sends a few more pixels through the exact re-walk)
+            if (!(Tend >= LG_T_MIN * 1.001f)) { sstar = s; break; }
+            const float in0 = T * r.y, in1 = T * r.z, in2 = T * r.w;
+            C0 += in0; C1 += in1; C2 += in2;
+            T = Tend;
+            last = ll ? ll : last;
+            ck[(size_t)s * 256] = make_float4(T, in0, in1, in2);   // what the backward starts segment s from
+        }
+        if (sstar == LG_NO_SEG) {
+            const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
+            final_T[pid] = T;
+            n_contrib[pid] = last;
+            out_color[pid] = fmaf(T, bg[0], C0);
+            out_color[HW + pid] = fmaf(T, bg[1], C1);
+            out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
+        } else {
+            ck[(size_t)sstar * 256] = make_float4(T, C0, C1, C2);
+            if (sstar > 0u) cl[(size_t)sstar * 256] = last;       // (s* = 0: nothing contributed before it)
+        }
+    }
+    cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
+}
+
 #define LG_PAR_GRID 1024   // persistent workgroups of the three long-tile kernels (they loop over the par_work items)
 __global__ void __launch_bounds__(256)
 lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                  const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,
-                 uint32_t* __restrict__ ckpt_last)
+                 uint32_t* __restrict__ ckpt_last, uint32_t* par_arrived, const float* __restrict__ bg, float* __restrict__ out_color,
+                 float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    __shared__ uint32_t s_last;
     const uint32_t nitems = meta[4];
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
@@ -352,63 +405,20 @@ lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ par_work
         const size_t slot = ((size_t)2 * (range.x / (uint32_t)S) + item.y) * 256 + pix;
         ckpt[slot] = make_float4(T, C0, C1, C2);
         ckpt_last[slot] = last;
-    }
-}
-
-// pass 2: per long tile, per pixel: prefix products over the segments.  A pixel whose transmittance never comes near the
-// termination threshold is finished here; one that would stop inside segment s* is parked -- {T before s*, colour so far} in
-// the checkpoint slot of s*, s* itself in the last-contributor word of slot 0 -- for lg_blend_fwd_rewalk.
-#define LG_NO_SEG 0xFFFFFFFFu
-__global__ void __launch_bounds__(256)
-lg_blend_fwd_scan(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
-                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                  float4* __restrict__ ckpt, uint32_t* __restrict__ ckpt_last)
-{
-    const uint32_t nitems = meta[4];
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const uint2 item = par_work[it];
-        if (item.y != 0u) continue;                                     // one scan per tile: the work item of its first segment
-        const int tile = (int)item.x;
-        const uint2 range = ranges[tile];
-        const uint32_t n = range.y - range.x;
-        const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
-        const int tx = tile % gx, ty = tile / gx;
-        const int pxi = tx * LG_TILE + (wave & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (wave >> 1) * 8 + (int)(lane >> 3);
-        const bool inside = pxi < W && pyi < H;
-        const uint32_t pix = ((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u);
-        float4* ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-        uint32_t* cl = ckpt_last + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix;
-        float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-        uint32_t last = 0, sstar = LG_NO_SEG;
-        if (inside) {
-            for (uint32_t s = 0; s < nseg; s++) {
-                const float4 r = ck[(size_t)s * 256];
-                const uint32_t ll = cl[(size_t)s * 256];
-                const float Tend = T * r.x;
-                // would this pixel stop inside the segment?  (T P_s < 1e-4 up to the rounding of the regrouped product: the margin
-                // only sends a few more pixels through the exact re-walk)
-                if (!(Tend >= LG_T_MIN * 1.001f)) { sstar = s; break; }
-                const float in0 = T * r.y, in1 = T * r.z, in2 = T * r.w;
-                C0 += in0; C1 += in1; C2 += in2;
-                T = Tend;
-                last = ll ? ll : last;
-                ck[(size_t)s * 256] = make_float4(T, in0, in1, in2);   // what the backward starts segment s from
-            }
-            if (sstar == LG_NO_SEG) {
-                const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
-                final_T[pid] = T;
-                n_contrib[pid] = last;
-                out_color[pid] = fmaf(T, bg[0], C0);
-                out_color[HW + pid] = fmaf(T, bg[1], C1);
-                out_color[2 * HW + pid] = fmaf(T, bg[2], C2);
-            } else {
-                ck[(size_t)sstar * 256] = make_float4(T, C0, C1, C2);
-                if (sstar > 0u) cl[(size_t)sstar * 256] = last;       // (s* = 0: nothing contributed before it)
-            }
+        // the last segment of this tile to arrive scans the tile (lg_scan_tile): release my records, count my arrival, and --
+        // if every segment of the tile is in -- acquire the others' records
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t nseg = (n + (uint32_t)S - 1u) / (uint32_t)S;
+            s_last = (__hip_atomic_fetch_add(&par_arrived[tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u) ? 1u : 0u;
         }
-        cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            lg_scan_tile(W, H, gx, S, tile, range, bg, out_color, final_T, n_contrib, ckpt, ckpt_last, wave, lane);
+        }
+        __syncthreads();                                            // (s_last is rewritten by the next item)
     }
 }
 

@@ -163,6 +163,7 @@ struct BinView {
     uint2* ranges;                  // [tiles]
     uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
     uint2* par_work;                // [tiles + R / S + 1] the items of the tiles whose list goes through the parallel long-tile forward
+    uint32_t* par_arrived;          // [tiles] per long tile: segments that finished pass 1 (the last one to arrive scans the tile)
     uint32_t* meta;                 // [16] 0 = number of work items, 1 = longest list of the view, 2 = S, 3 = par_min of the view
                                     //      (0 = none), 4 = number of par_work items (all written by lg_work_order_body)
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
@@ -189,6 +190,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, int seg)
     v.meta = (uint32_t*)take(64);                 // before anything whose size depends on S: the backward finds meta[2] (the forward's S) whatever S it was handed
     v.work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
     v.par_work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
+    v.par_arrived = (uint32_t*)take((size_t)gx * gy * 4);
     v.ckpt = (float4*)take(2 * (n / S + 1) * 256 * 16);
     v.ckpt_last = (uint32_t*)take(2 * (n / S + 1) * 256 * 4);
     v.entries = (uint64_t*)take(n * 8);
