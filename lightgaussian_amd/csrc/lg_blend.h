@@ -92,9 +92,15 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
     // hardware-exp variant: no clamp of the exponent -- lanes with power > 0 are rejected by `ok` below whatever exp returned
     // (inf -> alpha 0.99, NaN compares false), and the guard's rare branch clamps for itself
+#ifdef LG_ABL_NO_EXP              // ablation (timing only, wrong results): no transcendental
+    const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : (power * 0.01f + 0.5f);
+#else
     const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : __expf(power);
+#endif
     float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+#ifndef LG_ABL_NO_GUARD           // ablation (timing only): no threshold guard
     if (!EXACT) alpha = guard_alpha(alpha, b.y, power);
+#endif
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
@@ -679,14 +685,26 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
 #pragma clang fp contract(fast)
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
+#ifdef LG_ABL_NO_EXP              // ablation (timing only): no transcendental
+    const float G = power * 0.01f + 0.5f;
+#else
     const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
+#endif
     const float op = b.y;
+#ifdef LG_ABL_NO_GUARD            // ablation (timing only): no threshold guard
+    const float alpha = fminf(LG_ALPHA_MAX, op * G);
+#else
     const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
+#endif
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (S + 0 * d = S)
     // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
     const float am = ok ? alpha : 0.0f;
+#ifdef LG_ABL_NO_RCP              // ablation (timing only): no reciprocal
+    const float inv = 1.0f + am;
+#else
     const float inv = __builtin_amdgcn_rcpf(1.0f - am);
+#endif
     const float Tn = T * inv;
     // S = (colour accumulated behind this entry) . dL/dC of this pixel, carried as ONE scalar (round 3): the published
     // recurrence a <- a + alpha (c - a) is linear, so its projection on g obeys S <- S + alpha (c.g - S), and dL/dalpha only
@@ -867,7 +885,9 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
 #endif
                 }
                 if (cmask == 0) continue;
-#ifdef LG_K7_DPP_REDUCE
+#if defined(LG_ABL_NO_REDUCE)     // ablation (timing only, wrong results): no wave reduction
+                if (lane < 9) stage[j * 9 + lane] = p[0] + p[1] + p[2] + p[3] + p[4] + p[5] + p[6] + p[7] + p[8];
+#elif defined(LG_K7_DPP_REDUCE)
                 wave_reduce9_to_lds(p, stage + j * 9, lane);
 #else
                 wave_reduce9_via_lds(p, red, stage + j * 9, lane);
