@@ -565,6 +565,34 @@ __device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* 
 #define LG_RED_FLOATS (9 * LG_RED_STRIDE)
 __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float* red, float* dst, uint32_t lane)
 {
+#ifdef LG_K7_QUAD_PREREDUCE
+    // (A/B switch, round 3) quads are summed in registers first (2 DPP adds per value), so only every 4th lane writes and the
+    // read side is ONE ds_read_b128 per lane: a fifth of the LDS bytes for 6 more VALU instructions
+    float qsum[9];
+#pragma unroll
+    for (int v = 0; v < 9; v++) {
+        float t = dpp_add<0xB1, 0xf>(p[v]);
+        qsum[v] = dpp_add<0x4E, 0xf>(t);
+    }
+    if ((lane & 3u) == 0u) {
+#pragma unroll
+        for (int v = 0; v < 9; v++) red[v * 20 + (int)(lane >> 2)] = qsum[v];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const uint32_t r = min(lane >> 2, 8u), q = lane & 3u;
+        const float4 x = *reinterpret_cast<const float4*>(red + r * 20 + q * 4u);
+        float s = (x.x + x.y) + (x.z + x.w);
+        s = dpp_add<0xB1, 0xf>(s);
+        s = dpp_add<0x4E, 0xf>(s);
+        if (q == 0u && lane < 36u) dst[lane >> 2] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return;
+#endif
 #pragma unroll
     for (int v = 0; v < 9; v++) red[v * LG_RED_STRIDE + (int)lane] = p[v];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -573,8 +601,19 @@ __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float*
     const uint32_t r = min(lane >> 2, 8u), q = lane & 3u;
     const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
     const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+#ifdef LG_K7_PK_REDUCE
+    // (A/B switch, round 3) the 16 -> 1 sum as a tree of packed adds (v_pk_add_f32: 7 + 1 instructions instead of 15; a packed
+    // add costs 1.44x a plain one on gfx950, so ~37 instead of 45 issue cycles).  Another association than the default below.
+    typedef float lg_f2 __attribute__((ext_vector_type(2)));
+    const lg_f2 a0 = lg_f2{x0.x, x0.y} + lg_f2{x0.z, x0.w}, a1 = lg_f2{x1.x, x1.y} + lg_f2{x1.z, x1.w};
+    const lg_f2 a2 = lg_f2{x2.x, x2.y} + lg_f2{x2.z, x2.w}, a3 = lg_f2{x3.x, x3.y} + lg_f2{x3.z, x3.w};
+    const lg_f2 b0 = a0 + a1, b1 = a2 + a3;
+    const lg_f2 c0 = b0 + b1;
+    float s = c0.x + c0.y;
+#else
     float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
               (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+#endif
     s = dpp_add<0xB1, 0xf>(s);                      // quad_perm [1,0,3,2]
     s = dpp_add<0x4E, 0xf>(s);                      // quad_perm [2,3,0,1]: every lane of the quad holds the row total
     if (q == 0u && lane < 36u) dst[lane >> 2] = s;
