@@ -90,7 +90,7 @@ typedef struct lg_view {
     int32_t prefiltered;
     uint32_t flags;          /* LG_FLAG_* */
     int32_t segment_length;  /* per-tile lists longer than this many entries are processed by the backward as independent segments,
-                                from checkpoints the forward leaves (long-tile robustness).  0 = default (1024); otherwise a
+                                from checkpoints the forward leaves (long-tile robustness).  0 = default (512); otherwise a
                                 multiple of 64 (small values exist for tests).  The SAME lg_view must be handed to lg_forward* and
                                 to the lg_backward of that view, and to lg_binning_bytes: the forward records the value in the
                                 binning buffer and a backward called with another one writes zero gradients (LG_FLAG_DEBUG: error). */

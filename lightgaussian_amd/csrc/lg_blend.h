@@ -379,7 +379,10 @@ __device__ __forceinline__ void lg_scan_tile(int W, int H, int gx, int S, int ti
     cl[0] = sstar;                                                  // read by every (tile, segment) item of lg_blend_fwd_rewalk
 }
 
-#define LG_PAR_GRID 1024   // persistent workgroups of the three long-tile kernels (they loop over the par_work items)
+#ifndef LG_PAR_GRID
+#define LG_PAR_GRID 1024
+#endif
+//   // persistent workgroups of the three long-tile kernels (they loop over the par_work items)
 __global__ void __launch_bounds__(256)
 lg_blend_fwd_seg(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
                  const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,

@@ -150,13 +150,14 @@ static ImgView carve_img(void* base, int W, int H)
 // Long per-tile lists (real captures: tens of thousands of entries on a few tiles) are cut into SEGMENTS of S entries
 // (lg_view.segment_length, default LG_DEFAULT_SEGMENT): the forward leaves one checkpoint record per pixel at the end of every
 // segment of such a tile, and the backward runs one wave per (tile, segment) instead of one wave per tile -- a 20 000-entry
-// tile becomes ten independent work items instead of one 4 ms serial chain.  Tiles with at most one segment (all of the
-// uniform benchmark scene) never touch the checkpoints.  S is part of the VIEW (the caller passes the same lg_view to the
+// tile becomes ten independent work items instead of one 4 ms serial chain.  Tiles with at most one segment never
+// touch the checkpoints.  S is part of the VIEW (the caller passes the same lg_view to the
 // forward and to its backward; the forward also stores it in meta[2] and the backward kernels refuse to run on a mismatch):
-// the library keeps no state of its own.  1024 by measurement: in a dense pile every entry touches all four 8x8 blocks of the
-// tile, and a 2048-entry segment alone took 0.8 ms (heavy scene: K7 1.35 ms) -- longer than the whole uniform scene; lists of
-// the uniform benchmark scene stay below 1024.  64 / 128 exercise the machinery on small scenes (tests).
-#define LG_DEFAULT_SEGMENT 1024
+// the library keeps no state of its own.  512 by measurement (round 3; 1024 in round 2, when the forward walked long lists only
+// serially): fwd+bwd views/s at S = 1024 / 768 / 512 -- uniform benchmark scene 555 / 555 / 555, heavy-tailed scene 439 / 456 / 467, 6 M
+// Gaussians at 1600x1060 352 / 356 / 359, 3x larger splats 435 / 424 / 430.  In a dense pile every entry touches all four 8x8
+// blocks of the tile: a 2048-entry segment alone took 0.8 ms.  64 / 128 exercise the machinery on small scenes (tests).
+#define LG_DEFAULT_SEGMENT 512
 static inline int lg_segment_of(const lg_view* v) { return v->segment_length > 0 ? v->segment_length : LG_DEFAULT_SEGMENT; }
 
 struct BinView {

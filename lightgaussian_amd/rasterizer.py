@@ -55,7 +55,7 @@ def _validate(name, value):
     if name == "long_tiles" and value not in _LONG_TILES:
         raise ValueError(f"long_tiles must be one of {_LONG_TILES}")
     if name == "segment_length" and (int(value) < 0 or (int(value) != 0 and (int(value) < 64 or int(value) % 64))):
-        raise ValueError("segment_length must be 0 (library default, 1024) or a multiple of 64")
+        raise ValueError("segment_length must be 0 (library default, 512) or a multiple of 64")
 
 
 def set_option(name, value):
@@ -80,7 +80,7 @@ def set_option(name, value):
               is abandoned on the device; PendingBatch.resolve() / pending_status() (one sync for a whole batch of views)
               reports it and raises the capacity, and the caller re-renders -- parallel.backward_over_views and the sharded
               prune pass do;
-    segment_length: entries per backward segment of a long tile list (0 = the library default 1024; tests use 64 / 128);
+    segment_length: entries per backward segment of a long tile list (0 = the library default 512; tests use 64 / 128);
               travels in lg_view.segment_length, the backward of a view uses the value its forward ran with;
     long_tiles: "serial" | "auto" (default) | "parallel": walk of outlier tile lists in training forwards; "auto" is
               decided on the device from the view's own list statistics -- no dependence on earlier views."""

@@ -91,8 +91,8 @@ def test_the_library_has_no_process_wide_setters_and_the_segment_length_travels_
         with pytest.raises(AttributeError):
             getattr(C.CDLL(_lib.LIB_PATH), name)
     assert [f[0] for f in _lib.lg_view._fields_][-1] == "segment_length"
-    a, b = lib.lg_binning_bytes(100000, 640, 480, 0), lib.lg_binning_bytes(100000, 640, 480, 1024)
-    assert a == b > 0                                                   # 0 = the default of 1024
+    a, b = lib.lg_binning_bytes(100000, 640, 480, 0), lib.lg_binning_bytes(100000, 640, 480, 512)
+    assert a == b > 0                                                   # 0 = the default of 512
     assert lib.lg_binning_bytes(100000, 640, 480, 64) > a               # more checkpoint records for shorter segments
     assert lib.lg_binning_bytes(100000, 640, 480, 100) == 0             # not a multiple of 64
     assert lib.lg_binning_bytes(100000, 640, 480, 32) == 0              # below 64

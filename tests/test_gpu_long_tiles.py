@@ -97,7 +97,7 @@ def test_heavy_tailed_scene_has_long_lists_and_runs_with_the_default_segment():
     ranges = saved[-2][: T * 8].view(torch.int32).view(T, 2).cpu().numpy()
     n = ranges[:, 1] - ranges[:, 0]
     pkg["render"].sum().backward()
-    assert n.max() > 2 * 1024, n.max()                        # several segments on the densest tiles
+    assert n.max() > 4 * 512, n.max()                         # several segments on the densest tiles (default S = 512)
     assert torch.isfinite(pc._xyz.grad).all() and float(pc._xyz.grad.abs().sum()) > 0
 
 

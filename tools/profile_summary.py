@@ -39,7 +39,7 @@ ap.add_argument("--mode", required=True); ap.add_argument("--stats"); ap.add_arg
 ap.add_argument("--sq", nargs="*", default=[]); ap.add_argument("--command", default="")
 a = ap.parse_args()
 from lightgaussian_amd import _lib  # noqa: E402
-out = {"_meta": {"build_id": _lib.build_id(), "git_sha": os.environ.get("LG_GIT_SHA", "stamped at commit time by tools/stamp_profiles.py"),
+out = {"_meta": {"build_id": _lib.build_id(), "git_sha": os.environ.get("LG_GIT_SHA", "n/a (the GPU box receives a snapshot without .git; build_id identifies the sources)"),
                  "mode": a.mode, "command": a.command,
                  "workload": "C3: 3M synthetic Gaussians (seed 20250103), 1920x1080, SH degree 3, bench.py default path",
                  "notes": "avg_ns from rocprofv3 --kernel-trace --stats; fetch/write from separate --pmc FETCH_SIZE / WRITE_SIZE passes; "
