@@ -104,16 +104,18 @@ struct PinnedSlot {
 
 // Layout of the sort key of one view: tile | (depth bits - bias) >> store_drop | Gaussian id.  Exact forward: from the
 // read-back depth maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
-#ifndef LG_MIN_DEPTH_BITS
-#define LG_MIN_DEPTH_BITS 18
-#endif
 #define LG_NARROW_KEY_BITS 40   // LG_FLAG_NARROW_KEY (cross-check): lay the key out as if only this many bits were available
 struct KeyPlan {
     int tile_bits, gid_bits, depth_bits;   // field widths; depth_bits = width of the FULL depth pattern (minus bias) of this view
     int store_drop;                        // low depth bits that are not stored in the key (the fields exceed 64 bits): 0 at C3
-    int drop;                              // low STORED depth bits the radix passes skip; lg_tile_ranges finishes drop + store_drop bits
+    bool two_stage;                        // radix passes on the tile bits only + lg_tile_sort (default); false = LG_FLAG_SORT_ALL_BITS
     uint32_t gid_mask;
     int stored() const { return depth_bits - store_drop; }
+    int tile_shift() const { return gid_bits + stored(); }
+    // bit span of the global radix passes: the tile field (at least one bit: a single-tile image still needs its keys moved to the
+    // output buffer), preceded by every stored depth bit in the one-stage scheme
+    int sort_begin() const { return two_stage ? tile_shift() : gid_bits; }
+    int sort_end() const { return tile_shift() + (tile_bits > 0 ? tile_bits : 1); }
 };
 static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t flags)
 {
@@ -128,15 +130,11 @@ static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t fla
     // forward, the graph and the fused histograms.  At least one depth bit is always stored (tile <= 32 bits, id <= 29).
     const int avail = (flags & LG_FLAG_NARROW_KEY) ? LG_NARROW_KEY_BITS : 64;
     k.store_drop = std::max(0, std::min(k.depth_bits - 1, k.tile_bits + k.depth_bits + k.gid_bits - avail));
-    // The radix sort works in 8-bit passes.  The lowest `drop` stored depth bits are left to lg_tile_ranges as well whenever that
-    // saves whole passes and at least LG_MIN_DEPTH_BITS depth bits (sign-free float pattern: exponent + >= 13 mantissa bits at
-    // scene depths) stay in the sort: 39 -> 32 sorted bits at C3 (exact forward, 26 depth bits), 40 -> 32 in the bounded
-    // forward (27 bits for a zfar of 100).
-    k.drop = 0;
-    if (!(flags & LG_FLAG_SORT_ALL_BITS)) {
-        const int sorted = k.tile_bits + k.stored();
-        for (int d = sorted % 8; d <= k.stored() - LG_MIN_DEPTH_BITS; d += 8) k.drop = d;   // the largest admissible
-    }
+    // Two-stage sort (default, round 3): the global radix passes cover the tile bits only (13 bits at 1080p: two 8-bit passes
+    // instead of the four that tile + 19 depth bits took in round 2) and lg_tile_sort orders every list on ALL depth bits inside
+    // LDS.  LG_FLAG_SORT_ALL_BITS keeps the one-stage scheme -- every stored bit through the global passes, lg_tile_ranges
+    // finishing the bits a key beyond 64 bits does not store -- as an independent cross-check.
+    k.two_stage = !(flags & LG_FLAG_SORT_ALL_BITS);
     k.gid_mask = k.gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << k.gid_bits) - 1u);
     return k;
 }
@@ -188,7 +186,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     uint32_t k1_nclear = 0;
     if (bounded && N > 0 && cap > 0) {
         const LgSortLayout SL0 = lg_sort_layout((size_t)cap);
-        const int sb = kp.gid_bits + kp.drop, se = kp.gid_bits + kp.stored() + kp.tile_bits;
+        const int sb = kp.sort_begin(), se = kp.sort_end();
         k1_clear = (uint32_t*)bin.sort_temp;
         k1_nclear = (uint32_t)(lg_sort_clear_bytes(SL0, (unsigned)((se - sb + 7) / 8)) / 4);
     }
@@ -263,7 +261,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     g_stats.num_rendered = bounded ? -1 : R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
 
-    const int sort_begin = kp.gid_bits + kp.drop, sort_end = kp.gid_bits + kp.stored() + kp.tile_bits;
+    const int sort_begin = kp.sort_begin(), sort_end = kp.sort_end();
     if (cap > 0 && N > 0) {
         const LgSortLayout SL = lg_sort_layout((size_t)cap);
         // one clear for the digit histograms, the tile tickets and the look-back states of every radix pass (exact forward: the
@@ -286,10 +284,21 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         {
             ProfScope ps(prof, "tile_ranges", stream);
             const uint32_t rgrid = (uint32_t)((cap + 255) / 256);
-            lg_tile_ranges<<<rgrid, 256, 0, stream>>>(geo.counters, kp.stored() + kp.gid_bits, kp.gid_bits, kp.gid_mask, kp.drop, kp.store_drop,
-                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges, bounded ? bounded->status : nullptr);
+            lg_tile_ranges<<<rgrid, 256, 0, stream>>>(geo.counters, kp.tile_shift(), kp.gid_bits, kp.gid_mask, kp.two_stage ? 0 : kp.store_drop, kp.store_drop,
+                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges, bounded ? bounded->status : nullptr, bin.long_tiles);
         }
         KCHECK("lg_tile_ranges");
+        if (kp.two_stage) {
+            // second stage: one WAVE per tile orders its list by depth in LDS; lists beyond 1024 / 4096 entries go through persistent
+            // grids of 256- / 1024-thread workgroups (empty launches on scenes without such lists)
+            ProfScope ps(prof, "tile_sort", stream);
+            lg_tile_sort<<<ntiles, 64, 0, stream>>>(geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop, kp.depth_bits, geo.tinfo);
+            lg_tile_sort_mid<<<ntiles, LG_TS_THREADS, 0, stream>>>(geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop, kp.depth_bits,
+                                                                   geo.tinfo, bin.long_tiles);
+            lg_tile_sort_long<<<std::min(ntiles, LG_TL_GRID), LG_TL_THREADS, 0, stream>>>(geo.counters, bin.ranges, bin.entries, bin.keys_in, kp.gid_bits, kp.gid_mask,
+                                                                                          kp.store_drop, kp.depth_bits, geo.tinfo, bin.long_tiles);
+            KCHECK("lg_tile_sort");
+        }
     }
     const uint32_t gid_mask = kp.gid_mask;
     // (count / score accumulators of the count variant were cleared by lg_preprocess)

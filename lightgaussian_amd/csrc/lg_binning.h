@@ -1,4 +1,4 @@
-// lg_binning.h -- binning kernels: K2 lg_scan_blocks (+ depth maximum), K3 lg_duplicate (packed / pair keys, fused digit histograms), K5 lg_tile_ranges, lg_work_order
+// lg_binning.h -- binning kernels: K2 lg_scan_blocks (+ depth maximum), K3 lg_duplicate (packed keys, fused digit histograms), K5 lg_tile_ranges, lg_tile_sort (second sort stage), lg_work_order
 // Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
 #pragma once
 
@@ -234,12 +234,14 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
 }
 
 // K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised -- the blend kernels read
-// the sorted keys themselves) and completion of the order on the depth bits the radix sort did not cover:
-//   drop        low STORED depth bits the radix passes skipped to save a whole 8-bit pass (39 -> 32 sorted bits at C3: 5 -> 4)
+// the sorted keys themselves).  In the default TWO-STAGE sort (round 3) the radix passes before this kernel covered the tile bits
+// only and lg_tile_sort (below) orders every list by depth afterwards: finish_bits = 0, this kernel only finds the boundaries.
+// With LG_FLAG_SORT_ALL_BITS the radix passes covered every STORED depth bit too (the round-2 scheme, kept as the independent
+// cross-check of the tests) and this kernel completes the order on the bits a key beyond 64 bits does not store:
 //   store_drop  low depth bits that are not in the key at all (tile + depth + id beyond 64 bits): read from tinfo[id].z
-// Entries that agree on the sorted bits form runs that are still in emission (= id) order; ordering a run stably on its
-// low = drop + store_drop depth bits gives exactly the order a sort over all bits gives.  Short runs (<= 32 entries; depth
-// agrees to 2^-13 relative within one tile: about one pair per tile) are finished by their first thread with a stable
+// Entries that agree on the stored bits form runs that are still in emission (= id) order; ordering a run stably on its
+// finish_bits = store_drop low depth bits gives exactly the order a sort over all bits gives.  Short runs (<= 32 entries)
+// are finished by their first thread with a stable
 // insertion sort.  LONG runs -- a slab of coplanar splats puts thousands of entries at one depth; a narrow key (store_drop)
 // makes every run longer -- are finished by the WHOLE WAVE of the thread that found them: a stable LSD counting sort over the
 // low bits, 8 bits per pass (LDS digit counters, ballot-matched ranks, ping-pong with the free radix-sort input buffer), the
@@ -311,11 +313,12 @@ __device__ __forceinline__ void lg_wave_sort_run(uint32_t i, uint32_t e, int low
 }
 
 __global__ void __launch_bounds__(256)
-lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, uint32_t gid_mask, int drop, int store_drop,
+lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, uint32_t gid_mask, int finish_bits, int store_drop,
                uint64_t* entries /* the sorted keys */, uint64_t* scratch, const uint4* __restrict__ tinfo, uint2* __restrict__ ranges,
-               uint32_t* status /* lg_forward_bounded's status words, or NULL */)
+               uint32_t* status /* lg_forward_bounded's status words, or NULL */, uint32_t* __restrict__ long_tiles /* [0] = 0: the list lg_tile_sort_mid leaves to lg_tile_sort_long */)
 {
     __shared__ uint32_t s_cnt[4][256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) long_tiles[0] = 0u;
     if (counters[0] != 0u) {                       // view aborted (capacity-bounded forward, or the sort's look-back gave up)
         // K2 handed the caller its copy of the abort word BEFORE the sort ran: an abort raised by the sort is added here
         if (status && blockIdx.x == 0 && threadIdx.x == 0 && (counters[0] & LG_ABORT_SORT)) {
@@ -326,7 +329,7 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
     const uint32_t R = counters[3];                // the grid is sized for the capacity; the instance count lives on the device
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const int low_bits = drop + store_drop;
+    const int low_bits = finish_bits;              // 0 in the default two-stage sort: lg_tile_sort orders the lists
     bool mylong = false;
     uint32_t run_end = 0;
     if (i < R) {
@@ -341,8 +344,8 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
         }
         if (i == R - 1) ranges[t].y = R;
         if (low_bits > 0) {
-            const int fs = gid_bits + drop;
-            if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal sorted bits
+            const int fs = gid_bits;
+            if (i == 0 || (prev >> fs) != (key >> fs)) {            // first entry of a run of equal stored bits
                 uint32_t e = i + 1;
                 while (e < R && (entries[e] >> fs) == (key >> fs)) e++;
                 if (e - i > LG_RUN_SHORT) { mylong = true; run_end = e; }
@@ -367,6 +370,358 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
         big &= big - 1;
         const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)i, srcl), re = (uint32_t)__builtin_amdgcn_readlane((int)run_end, srcl);
         lg_wave_sort_run(ri, re, low_bits, gid_bits, gid_mask, store_drop, entries, scratch, tinfo, s_cnt[wave], lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second stage of the sort (round 3): every tile's list ordered by depth INSIDE the tile.
+// The global radix passes are bound by scattered 8-byte traffic and their own latency chain (0.035 ms per pass at C3 whatever
+// the digit), and a key needs tile + depth = 13 + 27 bits sorted: five passes, four with the low bits left to K5 (round 2).
+// But depth only has to be ordered among the ~500 entries of ONE tile, and those fit LDS: the global passes now cover the TILE
+// bits only (two passes) and the lists are finished tile by tile -- a stable LSD counting sort over ALL depth bits, 9 bits per
+// pass (three passes for 27 bits), entirely in LDS: keys in registers, per-wave digit counters, scan over waves and digits,
+// scatter into LDS, read back in list order.  The global passes are stable and lg_duplicate emits in id order, so a list arrives
+// in id order and a STABLE sort on depth gives exactly (depth, id) -- the order a sort over every key bit gives.  Depth bits a key
+// beyond 64 bits does not store (store_drop) come from the binning record (tinfo[id].z) in the passes that touch them;
+// coplanar slabs are just lists of equal digits.
+//   n <= 1024         lg_tile_sort       one WAVE per tile, no workgroup barrier (9 KB LDS: 16 tiles in flight per CU)
+//   n <= 4096         lg_tile_sort_mid   one 256-thread workgroup per tile (the same grid: the other tiles' workgroups return at once)
+//   longer            lg_tile_sort_long  1024-thread workgroups over the few tiles lg_tile_sort_mid lists: the same counting sort in
+//                                        chunks of 8192 entries, ping-pong between the list and the (free) radix-sort input buffer
+// Ranking without ballots: every lane ORs its lane bit into a 64-bit LDS word of its digit (ds_or_b64: commutative, so the result
+// does not depend on the order the hardware serves the lanes in) and reads the word back -- that IS the set of lanes of this
+// 64-key item with the same digit, which nine ballots + per-lane selects (~55 VALU instructions per item) would build.  The
+// lowest lane of each set bumps the wave's counter of the digit and clears the word.  In the two LDS-resident kernels the words
+// share LDS with the staging buffer (keys are in registers while they are ranked).
+#define LG_TS_DIGIT 9
+#define LG_TS_BINS (1 << LG_TS_DIGIT)
+#define LG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// bits [shift, shift + popc(dmask)) of the FULL depth pattern (minus bias) of a list entry; an all-ones key (padding) has all-ones digits
+__device__ __forceinline__ uint32_t lg_ts_digit(uint64_t key, int shift, uint32_t dmask, int gid_bits, uint32_t gid_mask, int store_drop,
+                                                const uint4* __restrict__ tinfo)
+{
+    // (shift + width never exceeds depth_bits, so the tile bits above the stored depth field are never reached)
+    if (shift >= store_drop) return (uint32_t)(key >> (gid_bits + shift - store_drop)) & dmask;                        // wave-uniform branch
+    if (key == ~0ull) return dmask;
+    return ((tinfo[(uint32_t)key & gid_mask].z - LG_DEPTH_BIAS) >> shift) & dmask;
+}
+
+// rank of a key among the keys of its wave's earlier items and lower lanes with the same digit.  mask = 512 zeroed 64-bit words
+// of this wave (zero again on return), wc = this wave's 16-bit digit counters.  Every lane takes part (padding keys included).
+__device__ __forceinline__ uint32_t lg_ts_rank(uint32_t d, unsigned long long* mask, unsigned short* wc, unsigned long long mybit)
+{
+    atomicOr(&mask[d], mybit);
+    LG_WAVE_SYNC();
+    const unsigned long long peers = mask[d];
+    const uint32_t prev = wc[d];
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+    LG_WAVE_SYNC();
+    if (below == 0u) { wc[d] = (unsigned short)(prev + (uint32_t)__popcll(peers)); mask[d] = 0ull; }   // the lowest lane of the set
+    LG_WAVE_SYNC();
+    return prev + below;
+}
+
+// pass plan shared by the three kernels: P = ceil(depth_bits / 9) passes of ceil(depth_bits / P) bits
+__device__ __forceinline__ int lg_ts_width(int depth_bits)
+{
+    const int passes = (depth_bits + LG_TS_DIGIT - 1) / LG_TS_DIGIT;
+    return (depth_bits + passes - 1) / passes;
+}
+
+#define LG_TW_ITEMS 16
+#define LG_TW_CAP (64 * LG_TW_ITEMS)
+__global__ void __launch_bounds__(64)
+lg_tile_sort(const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
+             int store_drop, int depth_bits, const uint4* __restrict__ tinfo)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t stage[LG_TW_CAP];           // staging buffer; its first 4 KB double as the digit lane masks
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[LG_TS_BINS];
+    if (counters[0] != 0u) return;                 // view aborted
+    const uint32_t lane = threadIdx.x;
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n < 2u || n > (uint32_t)LG_TW_CAP) return; // longer lists: lg_tile_sort_mid / _long
+    uint64_t* list = entries + r.x;
+    const uint32_t items = (n + 63u) >> 6;                                    // 1 .. LG_TW_ITEMS, wave-uniform
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(stage);
+    const unsigned long long mybit = 1ull << lane;
+    uint64_t key[LG_TW_ITEMS];
+    uint32_t rnk[LG_TW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < LG_TW_ITEMS; k++) {
+        const uint32_t idx = (uint32_t)k * 64u + lane;
+        key[k] = ((uint32_t)k < items && idx < n) ? list[idx] : ~0ull;        // padding sorts behind everything (and stays there: stable)
+    }
+    const int width = lg_ts_width(depth_bits);
+    for (int shift = 0; shift < depth_bits; shift += width) {
+        const uint32_t dmask = (1u << min(width, depth_bits - shift)) - 1u;
+        {   // clear the lane masks (4 KB) and the counters (1 KB): 16-byte stores
+            uint4* z = reinterpret_cast<uint4*>(stage);
+#pragma unroll
+            for (int i = 0; i < (LG_TS_BINS * 8) / (64 * 16); i++) z[(uint32_t)i * 64u + lane] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(cnt)[lane] = make_uint4(0, 0, 0, 0);
+        }
+        LG_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < LG_TW_ITEMS; k++) {
+            if ((uint32_t)k < items) {                                        // wave-uniform
+                const uint32_t d = lg_ts_digit(key[k], shift, dmask, gid_bits, gid_mask, store_drop, tinfo);
+                rnk[k] = lg_ts_rank(d, mask, cnt, mybit) | (d << 16);
+            }
+        }
+        {   // exclusive scan of the 512 counters: lane l owns digits 8 l .. 8 l + 7 (one 16-byte read, one 16-byte write)
+            const uint4 c = reinterpret_cast<const uint4*>(cnt)[lane];
+            const uint32_t c0 = c.x & 0xFFFFu, c1 = c.x >> 16, c2 = c.y & 0xFFFFu, c3 = c.y >> 16, c4 = c.z & 0xFFFFu, c5 = c.z >> 16, c6 = c.w & 0xFFFFu,
+                           c7 = c.w >> 16;
+            const uint32_t own = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+            uint32_t inc = own;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const uint32_t o = __shfl_up(inc, s, 64);
+                if ((int)lane >= s) inc += o;
+            }
+            const uint32_t e0 = inc - own, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2, e4 = e3 + c3, e5 = e4 + c4, e6 = e5 + c5, e7 = e6 + c6;
+            reinterpret_cast<uint4*>(cnt)[lane] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+        }
+        LG_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < LG_TW_ITEMS; k++)
+            if ((uint32_t)k < items) stage[(uint32_t)cnt[rnk[k] >> 16] + (rnk[k] & 0xFFFFu)] = key[k];
+        LG_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < LG_TW_ITEMS; k++)
+            if ((uint32_t)k < items) key[k] = stage[(uint32_t)k * 64u + lane];
+        LG_WAVE_SYNC();
+    }
+#pragma unroll
+    for (int k = 0; k < LG_TW_ITEMS; k++) {
+        const uint32_t idx = (uint32_t)k * 64u + lane;
+        if ((uint32_t)k < items && idx < n) list[idx] = key[k];
+    }
+}
+
+#define LG_TS_THREADS 256
+#define LG_TS_WAVES (LG_TS_THREADS / 64)
+#define LG_TS_ITEMS 16                                     // keys per thread: lists up to 4096 entries stay in LDS (32 KB)
+#define LG_TS_CAP (LG_TS_THREADS * LG_TS_ITEMS)
+static_assert(LG_TS_CAP < 65536, "16-bit LDS counters");
+__global__ void __launch_bounds__(LG_TS_THREADS)
+lg_tile_sort_mid(const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
+                 int store_drop, int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t stage[LG_TS_CAP];           // its first 16 KB double as the four waves' lane masks
+    __shared__ __attribute__((aligned(16))) unsigned short wcnt[LG_TS_WAVES][LG_TS_BINS];
+    __shared__ uint32_t lbase[LG_TS_BINS];
+    __shared__ uint32_t wtot[LG_TS_WAVES];
+    if (counters[0] != 0u) return;                 // view aborted
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n <= (uint32_t)LG_TW_CAP) return;          // lg_tile_sort's
+    if (n > (uint32_t)LG_TS_CAP) {
+        if (tid == 0) long_tiles[1u + atomicAdd(&long_tiles[0], 1u)] = blockIdx.x;
+        return;
+    }
+    uint64_t* list = entries + r.x;
+    const uint32_t items = (n + LG_TS_THREADS - 1u) / LG_TS_THREADS;          // 5 .. LG_TS_ITEMS, workgroup-uniform
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(stage) + wave * LG_TS_BINS;
+    const unsigned long long mybit = 1ull << lane;
+    uint64_t key[LG_TS_ITEMS];
+    uint32_t rnk[LG_TS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < LG_TS_ITEMS; k++) {
+        const uint32_t idx = (wave * items + (uint32_t)k) * 64u + lane;       // list order = (wave, item, lane)
+        key[k] = ((uint32_t)k < items && idx < n) ? list[idx] : ~0ull;
+    }
+    const int width = lg_ts_width(depth_bits);
+    for (int shift = 0; shift < depth_bits; shift += width) {
+        const uint32_t dmask = (1u << min(width, depth_bits - shift)) - 1u;
+        {   // clear the lane masks (16 KB) and the counters (4 KB)
+            uint4* z = reinterpret_cast<uint4*>(stage);
+#pragma unroll
+            for (int i = 0; i < (LG_TS_WAVES * LG_TS_BINS * 8) / (LG_TS_THREADS * 16); i++) z[(uint32_t)i * LG_TS_THREADS + tid] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(&wcnt[0][0])[tid] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LG_TS_ITEMS; k++) {
+            if ((uint32_t)k < items) {                                        // workgroup-uniform
+                const uint32_t d = lg_ts_digit(key[k], shift, dmask, gid_bits, gid_mask, store_drop, tinfo);
+                rnk[k] = lg_ts_rank(d, mask, wcnt[wave], mybit) | (d << 16);  // (rank < 1024; the digit rides along for the scatter)
+            }
+        }
+        __syncthreads();
+        // thread t owns digits 2 t and 2 t + 1: exclusive scan over the waves (written back), then over the digits
+        uint32_t run0 = 0, run1 = 0;
+#pragma unroll
+        for (int w = 0; w < LG_TS_WAVES; w++) {
+            uint32_t* pw = reinterpret_cast<uint32_t*>(&wcnt[w][0]) + tid;
+            const uint32_t pr = *pw;
+            *pw = run0 | (run1 << 16);
+            run0 += pr & 0xFFFFu; run1 += pr >> 16;
+        }
+        const uint32_t own = run0 + run1;
+        uint32_t inc = own;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = __shfl_up(inc, s, 64);
+            if ((int)lane >= s) inc += o;
+        }
+        if (lane == 63u) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < wave; w++) carry += wtot[w];
+        lbase[2u * tid] = carry + inc - own;
+        lbase[2u * tid + 1u] = carry + inc - own + run0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LG_TS_ITEMS; k++) {
+            if ((uint32_t)k < items) {
+                const uint32_t d = rnk[k] >> 16;
+                stage[lbase[d] + (uint32_t)wcnt[wave][d] + (rnk[k] & 0xFFFFu)] = key[k];
+            }
+        }
+        __syncthreads();
+        if (shift + width < depth_bits) {
+#pragma unroll
+            for (int k = 0; k < LG_TS_ITEMS; k++)
+                if ((uint32_t)k < items) key[k] = stage[(wave * items + (uint32_t)k) * 64u + lane];
+            __syncthreads();                       // every key read back before the masks are cleared over it
+        }
+    }
+    for (uint32_t q = tid; q < n; q += LG_TS_THREADS) list[q] = stage[q];
+}
+
+// Lists beyond LG_TS_CAP: persistent grid over the tiles lg_tile_sort_mid listed (none on most scenes: an empty launch).
+#define LG_TL_THREADS 1024
+#define LG_TL_WAVES (LG_TL_THREADS / 64)
+#define LG_TL_ITEMS 8
+#define LG_TL_CHUNK (LG_TL_THREADS * LG_TL_ITEMS)
+#ifndef LG_TL_GRID
+#define LG_TL_GRID 256
+#endif
+__global__ void __launch_bounds__(LG_TL_THREADS)
+lg_tile_sort_long(const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, uint64_t* scratch, int gid_bits,
+                  uint32_t gid_mask, int store_drop, int depth_bits, const uint4* __restrict__ tinfo, const uint32_t* long_tiles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long masks[LG_TL_WAVES][LG_TS_BINS];   // 64 KB
+    __shared__ __attribute__((aligned(16))) unsigned short wcnt[LG_TL_WAVES][LG_TS_BINS];        // 16 KB
+    __shared__ uint32_t gbase[LG_TS_BINS];       // position of the next key of digit d
+    __shared__ uint32_t gnext[LG_TS_BINS];       // digit totals of the next pass
+    __shared__ uint32_t wtot[4];
+    if (counters[0] != 0u) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nlong = long_tiles[0];
+    if (blockIdx.x >= nlong) return;
+    const unsigned long long mybit = 1ull << lane;
+    for (uint32_t i = tid; i < LG_TL_WAVES * LG_TS_BINS; i += LG_TL_THREADS) (&masks[0][0])[i] = 0ull;   // (zero again after every item)
+    const int width = lg_ts_width(depth_bits);
+    for (uint32_t item = blockIdx.x; item < nlong; item += gridDim.x) {
+        const uint2 r = ranges[long_tiles[1u + item]];
+        const uint32_t n = r.y - r.x;
+        uint64_t* src = entries + r.x;
+        uint64_t* dst = scratch + r.x;
+        // digit totals of the first pass: one counting pass over the list (eight loads in flight per thread); the totals of every
+        // later pass are counted while the pass before it scatters (the keys are in registers there)
+        if (tid < LG_TS_BINS) gnext[tid] = 0u;
+        __syncthreads();
+        {
+            const uint32_t dmask0 = (1u << min(width, depth_bits)) - 1u;
+            for (uint32_t i0 = 0; i0 < n; i0 += LG_TL_CHUNK) {
+                uint64_t kk[LG_TL_ITEMS];
+#pragma unroll
+                for (int k = 0; k < LG_TL_ITEMS; k++) {
+                    const uint32_t idx = i0 + (uint32_t)k * LG_TL_THREADS + tid;
+                    kk[k] = idx < n ? src[idx] : ~0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < LG_TL_ITEMS; k++)
+                    if (i0 + (uint32_t)k * LG_TL_THREADS + tid < n) atomicAdd(&gnext[lg_ts_digit(kk[k], 0, dmask0, gid_bits, gid_mask, store_drop, tinfo)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int shift = 0; shift < depth_bits; shift += width) {
+            const uint32_t dmask = (1u << min(width, depth_bits - shift)) - 1u;
+            const bool more = shift + width < depth_bits;
+            const uint32_t nmask = more ? (1u << min(width, depth_bits - shift - width)) - 1u : 0u;
+            // ---- exclusive scan of this pass's digit totals (gnext -> gbase; gnext restarts for the next pass) ----
+            uint32_t t0 = 0, t1 = 0, inc = 0;
+            if (tid < 256u) {
+                t0 = gnext[2u * tid]; t1 = gnext[2u * tid + 1u];
+                gnext[2u * tid] = 0u; gnext[2u * tid + 1u] = 0u;
+                inc = t0 + t1;
+#pragma unroll
+                for (int s = 1; s < 64; s <<= 1) {
+                    const uint32_t o = __shfl_up(inc, s, 64);
+                    if ((int)lane >= s) inc += o;
+                }
+                if (lane == 63u) wtot[wave] = inc;
+            }
+            __syncthreads();
+            if (tid < 256u) {
+                uint32_t carry = 0;
+                for (uint32_t w = 0; w < wave; w++) carry += wtot[w];
+                gbase[2u * tid] = carry + inc - (t0 + t1);
+                gbase[2u * tid + 1u] = carry + inc - t1;
+            }
+            // ---- phase B: chunk by chunk in list order ----
+            for (uint32_t c0 = 0; c0 < n; c0 += LG_TL_CHUNK) {
+                const uint32_t cn = min((uint32_t)LG_TL_CHUNK, n - c0);
+                for (uint32_t i = tid; i < LG_TL_WAVES * LG_TS_BINS / 2; i += LG_TL_THREADS) reinterpret_cast<uint32_t*>(&wcnt[0][0])[i] = 0u;
+                uint64_t key[LG_TL_ITEMS];
+                uint32_t rnk[LG_TL_ITEMS];
+#pragma unroll
+                for (int k = 0; k < LG_TL_ITEMS; k++) {
+                    const uint32_t idx = (wave * LG_TL_ITEMS + (uint32_t)k) * 64u + lane;
+                    key[k] = idx < cn ? src[c0 + idx] : ~0ull;
+                }
+                __syncthreads();                   // counters cleared; gbase of the previous chunk / of phase A complete
+#pragma unroll
+                for (int k = 0; k < LG_TL_ITEMS; k++) {
+                    if ((wave * LG_TL_ITEMS + (uint32_t)k) * 64u < cn) {                       // wave-uniform: items with any key
+                        const uint32_t d = lg_ts_digit(key[k], shift, dmask, gid_bits, gid_mask, store_drop, tinfo);
+                        rnk[k] = lg_ts_rank(d, masks[wave], wcnt[wave], mybit) | (d << 16);
+                    }
+                }
+                __syncthreads();
+                uint32_t run0 = 0, run1 = 0;
+                if (tid < 256u) {
+#pragma unroll
+                    for (int w = 0; w < LG_TL_WAVES; w++) {
+                        uint32_t* pw = reinterpret_cast<uint32_t*>(&wcnt[w][0]) + tid;
+                        const uint32_t pr = *pw;
+                        *pw = run0 | (run1 << 16);
+                        run0 += pr & 0xFFFFu; run1 += pr >> 16;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < LG_TL_ITEMS; k++) {
+                    const uint32_t idx = (wave * LG_TL_ITEMS + (uint32_t)k) * 64u + lane;
+                    if (idx < cn) {
+                        const uint32_t d = rnk[k] >> 16;
+                        dst[gbase[d] + (uint32_t)wcnt[wave][d] + (rnk[k] & 0xFFFFu)] = key[k];
+                        if (more) atomicAdd(&gnext[lg_ts_digit(key[k], shift + width, nmask, gid_bits, gid_mask, store_drop, tinfo)], 1u);
+                    }
+                }
+                __syncthreads();                   // every position of this chunk taken before the bases move
+                // (the padding keys of the last chunk were counted under the all-ones digit: nothing is placed behind them)
+                if (tid < 256u) { gbase[2u * tid] += run0; gbase[2u * tid + 1u] += run1; }
+            }
+            // the next pass (other waves of THIS workgroup) reads what this one wrote: workgroup scope is enough -- the waves share
+            // the CU's vector cache -- and far cheaper than an agent-scope release (an L2 write-back on a multi-XCD part)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint64_t* t = src; src = dst; dst = t;
+        }
+        if (src != entries + r.x) {
+            for (uint32_t i = tid; i < n; i += LG_TL_THREADS) entries[r.x + i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 

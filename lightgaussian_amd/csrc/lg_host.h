@@ -165,13 +165,14 @@ struct BinView {
     uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
     uint2* par_work;                // [tiles + R / S + 1] the items of the tiles whose list goes through the parallel long-tile forward
     uint32_t* par_arrived;          // [tiles] per long tile: segments that finished pass 1 (the last one to arrive scans the tile)
+    uint32_t* long_tiles;           // [1 + tiles] second sort stage: [0] = number of lists beyond a workgroup's LDS capacity, then their tiles (lg_tile_sort_mid -> _long)
     uint32_t* meta;                 // [16] 0 = number of work items, 1 = longest list of the view, 2 = S, 3 = par_min of the view
                                     //      (0 = none), 4 = number of par_work items (all written by lg_work_order_body)
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)
     uint32_t* ckpt_last;            // [2 (R / S + 1)][256] last contributing list position per (segment, pixel): pass 1 -> join of
                                     //     the parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk)
     uint64_t* entries;              // [R] sorted list entries = the sorted keys (tile | depth | id); the low bits_for(N) bits are the Gaussian id
-    uint64_t* keys_in;              // [R] radix-sort input; free after the sort: ping-pong buffer of lg_tile_ranges' long runs
+    uint64_t* keys_in;              // [R] radix-sort input; free after the sort: ping-pong buffer of lg_tile_sort_long / of lg_tile_ranges' long runs
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
 static int bits_for(uint32_t n) // smallest b with 2^b >= n
@@ -192,6 +193,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, int seg)
     v.work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
     v.par_work = (uint2*)take(((size_t)gx * gy + n / S + 1) * 8);
     v.par_arrived = (uint32_t*)take((size_t)gx * gy * 4);
+    v.long_tiles = (uint32_t*)take(((size_t)gx * gy + 1) * 4);
     v.ckpt = (float4*)take(2 * (n / S + 1) * 256 * 16);
     v.ckpt_last = (uint32_t*)take(2 * (n / S + 1) * 256 * 4);
     v.entries = (uint64_t*)take(n * 8);
