@@ -293,6 +293,12 @@ int lg_debug_sort_keys(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, i
 int lg_debug_last_contributor(const lg_view* view, int32_t N, const void* geom, const void* binning, const void* img, int64_t num_rendered,
                               uint32_t* out_ids, void* stream);
 
+/* diagnostics: the tile lists a forward with this view left in its binning buffer -- out_ranges [tiles][2] uint32 {begin, end} and
+ * out_entries [num_rendered] uint64 sorted keys (tile | depth | Gaussian id; only the first R = end of the last non-empty tile are
+ * meaningful).  The tests compare the default two-stage sort with the one-stage scheme (LG_FLAG_SORT_ALL_BITS) entry by entry. */
+int lg_debug_tile_lists(const lg_view* view, const void* binning, int64_t num_rendered, uint32_t* out_ranges, uint64_t* out_entries,
+                        void* stream);
+
 /* diagnostics: the failure path of the sort's look-back -- one digit pass whose only tile has a predecessor that never publishes.
  * Must return LG_ERR_DEVICE (error word set, no hang, no silent wrong order).  temp: lg_debug_sort_temp_bytes(2 * 8192). */
 int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, void* temp, void* stream);

@@ -759,6 +759,19 @@ lg_debug_last_contributor_kernel(int W, int H, int gx, const uint2* __restrict__
     const uint32_t n = counters[0] == 0u ? n_contrib[pid] : 0u;
     out[pid] = n > 0u ? ((uint32_t)entries[ranges[(y / LG_TILE) * gx + x / LG_TILE].x + n - 1u] & gid_mask) : 0xFFFFFFFFu;
 }
+extern "C" int lg_debug_tile_lists(const lg_view* v, const void* bin_p, int64_t R, uint32_t* out_ranges, uint64_t* out_entries, void* stream_p)
+{
+    if (!v || !bin_p || !out_ranges || !out_entries || R < 0 || v->image_width <= 0 || v->image_height <= 0)
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_debug_tile_lists: missing buffer");
+    const int W = v->image_width, H = v->image_height;
+    const size_t ntiles = (size_t)((W + LG_TILE - 1) / LG_TILE) * ((H + LG_TILE - 1) / LG_TILE);
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, W, H, lg_segment_of(v));
+    hipError_t e = hipMemcpyAsync(out_ranges, bin.ranges, ntiles * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream_p);
+    if (e == hipSuccess && R > 0) e = hipMemcpyAsync(out_entries, bin.entries, (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream_p);
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_tile_lists copy", e);
+    return LG_OK;
+}
+
 extern "C" int lg_debug_last_contributor(const lg_view* v, int32_t N, const void* geom_p, const void* bin_p, const void* img_p, int64_t R,
                                          uint32_t* out_ids, void* stream_p)
 {

@@ -8,9 +8,10 @@
 // computed by a pass over the keys: K3 (lg_duplicate) has every key in registers when it emits it and accumulates them
 // there (lg_sort_hist is the stand-alone form for other callers).
 //
-//   ranking      per wave and item (64 consecutive keys): lanes with equal digits find each other with 8 ballots
-//                ("match"), the lowest of them bumps the wave's 16-bit LDS counter of that digit; rank = old counter +
-//                number of equal lanes below.  Key order (wave, item, lane) = index order, so the sort is stable.
+//   ranking      per wave and item (64 consecutive keys): lanes with equal digits find each other through a 64-bit LDS
+//                word per (wave, digit) they OR their lane bit into (round 3; 8 ballots + selects before), the lowest of
+//                them bumps the wave's 16-bit LDS counter of that digit; rank = old counter + number of equal lanes
+//                below.  Key order (wave, item, lane) = index order, so the sort is stable.
 //   look-back    thread d owns digit d: state word = 2 flag bits | 30-bit count, one relaxed agent-scope store / load
 //                per word (the word is its own payload: no fence).  Tiles are numbered by an atomic ticket, so every
 //                predecessor a tile waits for is already running: no deadlock whatever the dispatch order.
@@ -44,6 +45,7 @@
 #endif
 static_assert(LG_SORT_BLOCK >= 256 && LG_SORT_BLOCK % 64 == 0, "one thread per digit needs >= 256 threads");
 static_assert(LG_SORT_ITEMS * 64 < 65536 && LG_SORT_TILE < 65536, "16-bit LDS counters");
+static_assert(LG_SORT_ITEMS >= 2, "the digit lane masks (waves x 256 x 8 B) live in the staging buffer (waves x items x 64 x 8 B)");
 
 // temp-storage layout: [hist 8 x 256 u32][tickets 8 u32 (64 B)][states passes x tiles x 256 u32][keys_tmp n u64]
 struct LgSortLayout {
@@ -121,6 +123,7 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
     const uint32_t n = counters ? counters[3] : n_arg;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     for (uint32_t i = tid; i < LG_SORT_WAVES * 256; i += LG_SORT_BLOCK) (&wcnt[0][0])[i] = 0;
+    for (uint32_t i = tid; i < LG_SORT_WAVES * 256; i += LG_SORT_BLOCK) stage[i] = 0ull;   // the waves' digit lane masks (ranking, below)
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint64_t tile_base = (uint64_t)tile * LG_SORT_TILE;
@@ -136,24 +139,31 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
         const uint32_t idx = (wave * LG_SORT_ITEMS + k) * 64u + lane;
         key[k] = idx < tile_n ? src[tile_base + idx] : ~0ull;
     }
+    // Lanes of one item (64 consecutive keys) with the same digit find each other through LDS: every lane ORs its lane bit into
+    // its wave's 64-bit word of that digit (ds_or_b64 -- commutative: the result does not depend on the order the hardware serves
+    // the lanes in) and reads the word back.  Round 2 built the same set with 8 ballots + per-lane selects, ~55 VALU instructions
+    // per item and almost half of the kernel's issue time.  The words live in `stage`, which is free until the reorder.
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(stage) + wave * 256u;
+    const unsigned long long mybit = 1ull << lane;
 #pragma unroll
     for (int k = 0; k < LG_SORT_ITEMS; k++) {
         const uint32_t idx = (wave * LG_SORT_ITEMS + k) * 64u + lane;
         const bool valid = idx < tile_n;
         const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        uint32_t prev = 0;
-        if (valid) prev = wcnt[wave][d];                                    // every peer reads the old count ...
+        if (valid) atomicOr(&mask[d], mybit);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0u) wcnt[wave][d] = (unsigned short)(prev + (uint32_t)__popcll(peers));   // ... the lowest one bumps it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long peers = 0;
+        uint32_t prev = 0;
+        if (valid) { peers = mask[d]; prev = wcnt[wave][d]; }               // every peer reads the set and the old count ...
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0u) {                                         // ... the lowest one bumps the count and clears the set
+            wcnt[wave][d] = (unsigned short)(prev + (uint32_t)__popcll(peers));
+            mask[d] = 0ull;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         rnk[k] = prev + below;

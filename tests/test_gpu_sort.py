@@ -99,3 +99,56 @@ def test_view_status_reads_the_abort_word_of_a_healthy_view():
     lib = _lib.load()
     _lib.check(lib.lg_view_status(geom.data_ptr(), 20000, C.byref(words), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert words[0] == 0 and words[3] > 0 and words[3] == _lib.last_stats()["num_rendered"]
+
+
+# ---- second stage of the view's sort: every tile's list ordered by depth inside LDS (lg_tile_sort / _mid / _long) ----
+def _tile_lists(image, W, H):
+    """(ranges [tiles, 2], entries [R] uint64) of the view that produced `image`, from the binning buffer its forward saved."""
+    from lightgaussian_amd import rasterizer
+    fn = image.grad_fn
+    *_, radii, geom, binning, img = fn.saved_tensors
+    call = rasterizer._Call(fn.raster_settings, fn.saved_tensors[0], None, None, None, None, None, None, exact=False, opts=fn.opts)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    R = int(fn.num_rendered)
+    ranges = torch.empty(T * 2, dtype=torch.int32, device=image.device)
+    entries = torch.empty(max(R, 1), dtype=torch.int64, device=image.device)
+    _lib.check(_lib.load().lg_debug_tile_lists(C.byref(call.view), binning.data_ptr(), R, ranges.data_ptr(), entries.data_ptr(),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ranges = ranges.cpu().numpy().reshape(T, 2).astype(np.int64)
+    return ranges, entries.cpu().numpy().view(np.uint64)[: int(ranges[:, 1].max())]
+
+
+def test_two_stage_sort_gives_the_lists_of_the_one_stage_sort_in_every_length_class():
+    """Default: radix passes on the tile bits + one LDS counting sort per tile (a wave for lists up to 1024 entries, a workgroup up
+    to 4096, the chunked 1024-thread kernel beyond).  LG_SORT_ALL_BITS=1: every bit through the global radix passes (round 2).
+    Both must leave the same lists, entry for entry, and every list strictly ascending in (depth, id)."""
+    import os
+    from lightgaussian_amd import synthetic as syn
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device(DEV)
+    W, H = 640, 368
+    g = syn.make_gaussians(300_000, seed=12)
+    syn.make_heavy_tailed(g, frac=0.1)
+    pc = g.to(dev).requires_grad_(True)
+    cam = syn.orbit_camera(1, 10, W, H).to(dev)
+    lists = {}
+    for mode in ("two_stage", "one_stage"):
+        if mode == "one_stage":
+            os.environ["LG_SORT_ALL_BITS"] = "1"
+        try:
+            pkg = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))
+            lists[mode] = _tile_lists(pkg["render"], W, H) + (pkg["render"].detach().cpu().numpy(),)
+        finally:
+            os.environ.pop("LG_SORT_ALL_BITS", None)
+    (ra, ea, ia), (rb, eb, ib) = lists["two_stage"], lists["one_stage"]
+    n = ra[:, 1] - ra[:, 0]
+    assert ((n > 1) & (n <= 1024)).any() and ((n > 1024) & (n <= 4096)).any() and (n > 4096).any(), (int(n.max()), np.percentile(n, [50, 90, 99]))
+    assert np.array_equal(ra, rb)
+    # (the two renders may lay their keys out differently -- the exact forward sizes the depth field from the view's own depth
+    #  maximum, the bounded one from the caller's bound -- so the lists are compared by Gaussian id, the low bits_for(N) key bits)
+    idm = np.uint64((1 << (g.num - 1).bit_length()) - 1)
+    assert ea.shape == eb.shape and np.array_equal(ea & idm, eb & idm), f"{int(((ea & idm) != (eb & idm)).sum())} of {ea.size} entries differ"
+    assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
+    # the key is tile | depth | id with nothing dropped at this size, so the u64 order IS (tile, depth, id): the whole array ascends
+    assert (ea[1:] > ea[:-1]).all() and (eb[1:] > eb[:-1]).all()
