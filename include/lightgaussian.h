@@ -59,9 +59,11 @@ enum {
                               undefined); counts, scores and radii are unaffected.  Used by the sharded prune pass. */
     LG_FLAG_L1_ONLY = 32,  /* lg_loss_forward / lg_loss_backward only: mean |img - gt| without the SSIM work (out[1] = 0);
                               forward and backward must agree */
-    LG_FLAG_NARROW_KEY = 64,     /* cross-check switches (never needed in production): lay the sort key out as if only */
-    LG_FLAG_SORT_ALL_BITS = 128, /* 40 bits were available (exercises the beyond-64-bit layout on small scenes); sort every stored depth */
-    LG_FLAG_K1_LDS = 256,        /* bit (no completion of skipped bits in K5); K1 stages SH rows through LDS instead of per-lane reads */
+    /* cross-check switches (never needed in production): */
+    LG_FLAG_NARROW_KEY = 64,     /* lay the sort key out as if only 40 bits were available (exercises the beyond-64-bit layout on small scenes) */
+    LG_FLAG_SORT_ALL_BITS = 128, /* one-stage sort: every stored key bit through the global radix passes (the round-2 scheme) instead of the
+                                    default two stages -- radix passes on the tile bits, then each list ordered by depth inside LDS.  Same lists. */
+    LG_FLAG_K1_LDS = 256,        /* K1 stages SH rows through LDS instead of per-lane reads */
     LG_FLAG_LONG_SERIAL = 512,   /* long per-tile lists of the hardware-exp colour forward: walk every list serially inside the blend kernel */
     LG_FLAG_LONG_PARALLEL = 1024, /* ... walk the segments of EVERY multi-segment list in parallel (lg_blend_fwd_seg / _scan / _rewalk).
                               Neither flag (default): only lists longer than two segments and four times the view's mean list --

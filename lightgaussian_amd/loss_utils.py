@@ -43,6 +43,7 @@ class _L1SSIM(torch.autograd.Function):
         _lib.check(lib.lg_loss_forward(planes, H, W, img.data_ptr(), gt.data_ptr(), state.data_ptr(), out.data_ptr(), flags,
                                        C.c_void_p(stream)))
         ctx.save_for_backward(img, gt, state)
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None (the backward handles it), not as a filled zero
         ctx.dims = (planes, H, W)
         ctx.token = {"consumed": False}      # shared with the memo of _both(): a graph that ran backward is not handed out again
         _memo.token = ctx.token              # forward runs on the caller's thread: handed to _both() through ITS thread-local slot
