@@ -298,6 +298,10 @@ int lg_debug_last_contributor(const lg_view* view, int32_t N, const void* geom, 
 /* diagnostics: the tile lists a forward with this view left in its binning buffer -- out_ranges [tiles][2] uint32 {begin, end} and
  * out_entries [num_rendered] uint64 sorted keys (tile | depth | Gaussian id; only the first R = end of the last non-empty tile are
  * meaningful).  The tests compare the default two-stage sort with the one-stage scheme (LG_FLAG_SORT_ALL_BITS) entry by entry. */
+/* Byte offset, inside the geom buffer of a forward over N Gaussians, of uint8 visible[N] (1 = radii > 0): the reference's
+ * `visibility_filter = radii > 0` (gaussian_renderer/__init__.py:121) without a kernel of its own. */
+size_t lg_geom_visible_offset(int32_t N);
+
 int lg_debug_tile_lists(const lg_view* view, const void* binning, int64_t num_rendered, uint32_t* out_ranges, uint64_t* out_entries,
                         void* stream);
 

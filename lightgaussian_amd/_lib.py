@@ -30,7 +30,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
            "lg_debug_sort_keys", "lg_build_id", "lg_backward_chunked", "lg_debug_activations", "lg_view_status",
-           "lg_debug_sort_orphan", "lg_debug_last_contributor", "lg_debug_tile_lists"]
+           "lg_debug_sort_orphan", "lg_debug_last_contributor", "lg_debug_tile_lists", "lg_geom_visible_offset"]
 
 
 class lg_view(C.Structure):
@@ -133,6 +133,7 @@ def load():
     lib.lg_debug_last_contributor.restype = C.c_int
     lib.lg_debug_last_contributor.argtypes = [P(lg_view), C.c_int32, vp, vp, vp, C.c_int64, vp, vp]
     lib.lg_debug_sort_orphan.restype = C.c_int; lib.lg_debug_sort_orphan.argtypes = [C.c_int64, vp, vp, vp, vp]
+    lib.lg_geom_visible_offset.restype = C.c_size_t; lib.lg_geom_visible_offset.argtypes = [C.c_int32]
     lib.lg_debug_tile_lists.restype = C.c_int; lib.lg_debug_tile_lists.argtypes = [P(lg_view), vp, C.c_int64, vp, vp, vp]
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
     lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []

@@ -104,6 +104,7 @@ struct PinnedSlot {
 
 // Layout of the sort key of one view: tile | (depth bits - bias) >> store_drop | Gaussian id.  Exact forward: from the
 // read-back depth maximum.  Bounded forward: from the caller's depth bound (nothing is read back).
+#define LG_STATUS_PENDING 0xFFFFFFFFu   // sentinel of the host-visible status word 0 (a real abort word has only its low bits set)
 #define LG_NARROW_KEY_BITS 40   // LG_FLAG_NARROW_KEY (cross-check): lay the key out as if only this many bits were available
 struct KeyPlan {
     int tile_bits, gid_bits, depth_bits;   // field widths; depth_bits = width of the FULL depth pattern (minus bias) of this view
@@ -181,6 +182,16 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream));
         }
     }
+    // validated bounded forward: K2 writes its four status words STRAIGHT into pinned host memory (system-scope release on word 0,
+    // as it does for graph.GraphedStep) and the host waits for word 0 to leave its sentinel once everything of the view has been
+    // enqueued -- no device-to-host copy node behind K2 (a 4 us blit kernel + its launch gap on the critical path of every view)
+    PinnedSlot vslot;
+    const bool host_words = bounded && bounded->host_status;
+    if (host_words) {
+        if (!vslot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the status slot failed");
+        if (N > 0) { vslot.p[1] = vslot.p[2] = vslot.p[3] = 0u; __atomic_store_n(&vslot.p[0], LG_STATUS_PENDING, __ATOMIC_RELEASE); }
+        else memset(vslot.p, 0, 16);
+    }
     // bounded forward: K1 also clears the sort's histograms / tickets / states (the buffer and the key layout are known already)
     uint32_t* k1_clear = nullptr;
     uint32_t k1_nclear = 0;
@@ -217,12 +228,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
                                                                                   geo.part_dmax, geo.part_prefix, geo.counters + 8,
                                                                                   bounded ? (uint32_t)cap : 0xFFFFFFFFu,
                                                                                   bounded ? kp.depth_bits : 32, geo.counters,
-                                                                                  bounded ? (uint32_t*)bounded->status : nullptr);
+                                                                                  host_words ? vslot.p : (bounded ? (uint32_t*)bounded->status : nullptr));
         }
         KCHECK("lg_scan_blocks");
     }
     int64_t R = cap;
-    PinnedSlot vslot;          // (validated bounded forward)
     if (!bounded) {
         uint32_t h_counters[4] = {0, 0, 0, 0};
         if (N > 0) {
@@ -249,14 +259,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (R == 0) HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream)); // otherwise cleared by lg_duplicate
     } else {
         // (bounded->status is written by lg_scan_blocks itself, or cleared above for N == 0: no copy node)
-        if (bounded->host_status) {
-            // validated mode: the four status words travel to pinned host memory right behind K2; the host waits for them
-            // only AFTER everything else of the view has been enqueued (end of this function), so the device never idles
-            if (!vslot.p) return fail(LG_ERR_ALLOC, "hipHostMalloc of the read-back slot failed");
-            if (N > 0) HIP_TRY(hipMemcpyAsync(vslot.p, geo.counters, 16, hipMemcpyDeviceToHost, stream));
-            else memset(vslot.p, 0, 16);
-            HIP_TRY(hipEventRecord(vslot.ev, stream));
-        }
+        // (validated mode: K2 wrote the words into vslot.p itself; the host looks at them at the end of this function)
     }
     g_stats.num_rendered = bounded ? -1 : R;
     g_stats.num_visible = -1; // not tracked on the device (see lg_preprocess); callers count radii > 0
@@ -354,8 +357,23 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (h_abort & LG_ABORT_SORT) return fail(LG_ERR_DEVICE, "radix sort look-back gave up (a predecessor tile never published): the view is void");
     }
     if (bounded && bounded->host_status) {
-        HIP_TRY(hipEventSynchronize(vslot.ev));            // K2's words are here; the blend kernels are still running
-        for (int k = 0; k < 4; k++) bounded->host_status[k] = vslot.p[k];
+        // K2's words arrive while the blend kernels are still running.  Spin on word 0 (written last, released system-wide); every
+        // few thousand polls ask the stream whether it is still working, so that a device error cannot turn into a host hang
+        uint32_t w0 = __atomic_load_n(&vslot.p[0], __ATOMIC_ACQUIRE);
+        for (uint64_t spins = 1; w0 == LG_STATUS_PENDING; spins++) {
+            if ((spins & 0xFFFu) == 0u) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipErrorNotReady) {                       // stream drained (or failed): the words are final
+                    w0 = __atomic_load_n(&vslot.p[0], __ATOMIC_ACQUIRE);
+                    if (w0 == LG_STATUS_PENDING) return fail(LG_ERR_DEVICE, "lg_forward_bounded: the status words never arrived", q);
+                    break;
+                }
+            }
+            __builtin_ia32_pause();
+            w0 = __atomic_load_n(&vslot.p[0], __ATOMIC_ACQUIRE);
+        }
+        bounded->host_status[0] = w0;
+        for (int k = 1; k < 4; k++) bounded->host_status[k] = vslot.p[k];
         g_stats.num_rendered = vslot.p[3];
     }
     return LG_OK;

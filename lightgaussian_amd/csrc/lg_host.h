@@ -98,6 +98,7 @@ struct GeomView {
     uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
     uint32_t* touched;  // [N]  instance count per Gaussian (K1)
     uint32_t* offsets;  // [N]  inclusive scan of touched (written by K3; K9 derives the slot base from it)
+    uint8_t* visible;   // [N]  1 = radius > 0 (K1): the render package's visibility_filter, read in place through lg_geom_visible_offset()
     uint32_t* counters; // [16] per-view device words: 0 = abort flags, 1 = prefiltered violation, 2 = largest depth bit
                         //      pattern, 3 = instance count R (all written by lg_scan_blocks); 8 = arrival counter of
                         //      lg_scan_blocks (zeroed by K1, left at zero by the scan)
@@ -119,6 +120,7 @@ static GeomView carve_geom(void* base, int N)
     g.tinfo = (uint4*)take(n * 16);
     g.touched = (uint32_t*)take(n * 4);
     g.offsets = (uint32_t*)take(n * 4);
+    g.visible = (uint8_t*)take(n);
     g.counters = (uint32_t*)take(64);
     g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
     g.blk_sum = (uint32_t*)take(((n + 63) / 64) * 4);
@@ -206,6 +208,7 @@ static BinView carve_bin(void* base, int64_t R, int W, int H, int seg)
 }
 
 extern "C" size_t lg_geom_bytes(int32_t N) { return carve_geom(nullptr, N).total; }
+extern "C" size_t lg_geom_visible_offset(int32_t N) { return (size_t)((char*)carve_geom((void*)256, N).visible - (char*)256); }
 extern "C" size_t lg_img_bytes(int32_t W, int32_t H) { return carve_img(nullptr, W, H).total; }
 extern "C" size_t lg_binning_bytes(int64_t R, int32_t W, int32_t H, int32_t segment_length)
 {

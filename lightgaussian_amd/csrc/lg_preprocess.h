@@ -189,6 +189,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                                     __float_as_uint(sp.depth), 0u);
         }
         radii[i] = radius;
+        g.visible[i] = radius > 0 ? (uint8_t)1 : (uint8_t)0;
         g.touched[i] = touched;
     }
     // The records of the workgroup's 64 Gaussians are contiguous in rec: staged in LDS and written as coalesced

@@ -150,7 +150,8 @@ def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mod
         return _render_unfused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, options)
     screenspace_points = _screenspace_points(pc)
     rs = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, False)
-    rendered_image, radii = rasterize_gaussians_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
-                                                    pc._scaling, pc._rotation, rs, options)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+    rendered_image, radii, visible = rasterize_gaussians_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
+                                                             pc._scaling, pc._rotation, rs, options)
+    # visibility_filter = radii > 0 (gaussian_renderer/__init__.py:121), as K1 left it in the forward's geom buffer: no compare kernel
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": visible,
             "radii": radii}

@@ -480,12 +480,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.has_rest = rest is not None
         ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
         ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, binning, img)
-        ctx.mark_non_differentiable(radii)
+        # visibility_filter (= radii > 0, gaussian_renderer/__init__.py:121) read in place: K1 leaves it as bytes in the geom buffer
+        off = lib.lg_geom_visible_offset(call.N)
+        visible = geom[off:off + call.N].view(torch.bool)
+        ctx.mark_non_differentiable(radii, visible)
         ctx.set_materialize_grads(False)               # (see _RasterizeGaussians.forward)
-        return color, radii
+        return color, radii, visible
 
     @staticmethod
-    def backward(ctx, grad_color, _grad_radii):
+    def backward(ctx, grad_color, _grad_radii, _grad_visible=None):
         lib = _lib.load()
         rs = ctx.raster_settings
         xyz, dc, rest, opac, scales, rots, radii, geom, binning, img = ctx.saved_tensors

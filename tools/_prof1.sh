@@ -6,6 +6,6 @@ S=$(find /tmp/p1 -name '*kernel_stats.csv' | head -1)
 echo "== $extra"; python - "$S" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'lg_' in r['Name'][:12] : print(r['Name'][:40], r['Calls'], round(float(r['AverageNs'])/1e3,1), 'us')
+    print(r['Name'][:40], r['Calls'], round(float(r['AverageNs'])/1e3,1), 'us')
 PY
 done
