@@ -292,12 +292,11 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         }
         KCHECK("lg_tile_ranges");
         if (kp.two_stage) {
-            // second stage: one WAVE per tile orders its list by depth in LDS; lists beyond 1024 / 4096 entries go through persistent
-            // grids of 256- / 1024-thread workgroups (empty launches on scenes without such lists)
+            // second stage: one WAVE per tile orders its list by depth in LDS (lists up to 1024 entries; up to 4096: a whole workgroup,
+            // same launch); the few longer ones go through a persistent grid of 1024-thread workgroups (an empty launch otherwise)
             ProfScope ps(prof, "tile_sort", stream);
-            lg_tile_sort<<<ntiles, 64, 0, stream>>>(geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop, kp.depth_bits, geo.tinfo);
-            lg_tile_sort_mid<<<ntiles, LG_TS_THREADS, 0, stream>>>(geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop, kp.depth_bits,
-                                                                   geo.tinfo, bin.long_tiles);
+            lg_tile_sort<<<(ntiles + 3) / 4 + ntiles, LG_TS_THREADS, 0, stream>>>(ntiles, geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop,
+                                                                                  kp.depth_bits, geo.tinfo, bin.long_tiles);
             lg_tile_sort_long<<<std::min(ntiles, LG_TL_GRID), LG_TL_THREADS, 0, stream>>>(geo.counters, bin.ranges, bin.entries, bin.keys_in, kp.gid_bits, kp.gid_mask,
                                                                                           kp.store_drop, kp.depth_bits, geo.tinfo, bin.long_tiles);
             KCHECK("lg_tile_sort");

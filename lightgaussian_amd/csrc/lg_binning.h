@@ -385,8 +385,8 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 // beyond 64 bits does not store (store_drop) come from the binning record (tinfo[id].z) in the passes that touch them;
 // coplanar slabs are just lists of equal digits.
 //   n <= 1024         lg_tile_sort       one WAVE per tile, no workgroup barrier (9 KB LDS: 16 tiles in flight per CU)
-//   n <= 4096         lg_tile_sort_mid   one 256-thread workgroup per tile (the same grid: the other tiles' workgroups return at once)
-//   longer            lg_tile_sort_long  1024-thread workgroups over the few tiles lg_tile_sort_mid lists: the same counting sort in
+//   n <= 4096         (same launch)      one 256-thread workgroup per tile (extra workgroups of the grid: those of other tiles return at once)
+//   longer            lg_tile_sort_long  1024-thread workgroups over the few tiles the workgroup path lists: the same counting sort in
 //                                        chunks of 8192 entries, ping-pong between the list and the (free) radix-sort input buffer
 // Ranking without ballots: every lane ORs its lane bit into a 64-bit LDS word of its digit (ds_or_b64: commutative, so the result
 // does not depend on the order the hardware serves the lanes in) and reads the word back -- that IS the set of lanes of this
@@ -431,17 +431,15 @@ __device__ __forceinline__ int lg_ts_width(int depth_bits)
 
 #define LG_TW_ITEMS 16
 #define LG_TW_CAP (64 * LG_TW_ITEMS)
-__global__ void __launch_bounds__(64)
-lg_tile_sort(const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
-             int store_drop, int depth_bits, const uint4* __restrict__ tinfo)
+// one wave, one list of up to LG_TW_CAP entries.  stage = LG_TW_CAP keys of LDS (its first 4 KB double as the digit lane masks),
+// cnt = 512 16-bit counters -- this wave's own: no workgroup barrier anywhere in here
+__device__ __forceinline__ void lg_tile_sort_wave(uint32_t tile, uint32_t lane, uint64_t* stage, unsigned short* cnt, const uint2* __restrict__ ranges,
+                                                  uint64_t* entries, int gid_bits, uint32_t gid_mask, int store_drop, int depth_bits,
+                                                  const uint4* __restrict__ tinfo)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t stage[LG_TW_CAP];           // staging buffer; its first 4 KB double as the digit lane masks
-    __shared__ __attribute__((aligned(16))) unsigned short cnt[LG_TS_BINS];
-    if (counters[0] != 0u) return;                 // view aborted
-    const uint32_t lane = threadIdx.x;
-    const uint2 r = ranges[blockIdx.x];
+    const uint2 r = ranges[tile];
     const uint32_t n = r.y - r.x;
-    if (n < 2u || n > (uint32_t)LG_TW_CAP) return; // longer lists: lg_tile_sort_mid / _long
+    if (n < 2u || n > (uint32_t)LG_TW_CAP) return; // longer lists: the workgroup / lg_tile_sort_long paths
     uint64_t* list = entries + r.x;
     const uint32_t items = (n + 63u) >> 6;                                    // 1 .. LG_TW_ITEMS, wave-uniform
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(stage);
@@ -506,21 +504,18 @@ lg_tile_sort(const uint32_t* __restrict__ counters, const uint2* __restrict__ ra
 #define LG_TS_ITEMS 16                                     // keys per thread: lists up to 4096 entries stay in LDS (32 KB)
 #define LG_TS_CAP (LG_TS_THREADS * LG_TS_ITEMS)
 static_assert(LG_TS_CAP < 65536, "16-bit LDS counters");
-__global__ void __launch_bounds__(LG_TS_THREADS)
-lg_tile_sort_mid(const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
-                 int store_drop, int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles)
+// one 256-thread workgroup, one list of LG_TW_CAP < n <= LG_TS_CAP entries.  stage = LG_TS_CAP keys of LDS (its first 16 KB double
+// as the four waves' lane masks)
+__device__ __forceinline__ void lg_tile_sort_wg(uint32_t tile, uint64_t* stage, unsigned short (*wcnt)[LG_TS_BINS], uint32_t* lbase, uint32_t* wtot,
+                                                const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask, int store_drop,
+                                                int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t stage[LG_TS_CAP];           // its first 16 KB double as the four waves' lane masks
-    __shared__ __attribute__((aligned(16))) unsigned short wcnt[LG_TS_WAVES][LG_TS_BINS];
-    __shared__ uint32_t lbase[LG_TS_BINS];
-    __shared__ uint32_t wtot[LG_TS_WAVES];
-    if (counters[0] != 0u) return;                 // view aborted
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint2 r = ranges[blockIdx.x];
+    const uint2 r = ranges[tile];
     const uint32_t n = r.y - r.x;
-    if (n <= (uint32_t)LG_TW_CAP) return;          // lg_tile_sort's
+    if (n <= (uint32_t)LG_TW_CAP) return;          // a wave's
     if (n > (uint32_t)LG_TS_CAP) {
-        if (tid == 0) long_tiles[1u + atomicAdd(&long_tiles[0], 1u)] = blockIdx.x;
+        if (tid == 0) long_tiles[1u + atomicAdd(&long_tiles[0], 1u)] = tile;
         return;
     }
     uint64_t* list = entries + r.x;
@@ -593,7 +588,35 @@ lg_tile_sort_mid(const uint32_t* __restrict__ counters, const uint2* __restrict_
     for (uint32_t q = tid; q < n; q += LG_TS_THREADS) list[q] = stage[q];
 }
 
-// Lists beyond LG_TS_CAP: persistent grid over the tiles lg_tile_sort_mid listed (none on most scenes: an empty launch).
+// ONE launch for both: workgroups [0, ceil(tiles / 4)) are four independent waves with a tile each (wave-synchronous code only:
+// no workgroup barrier), workgroups [ceil(tiles / 4), + tiles) take one tile each as a whole and return at once unless its list
+// is of the middle class -- so the second class costs the uniform scene no launch of its own (an empty launch and its gap: ~9 us).
+#define LG_TS_SMEM_STAGE (LG_TS_CAP * 8)
+#define LG_TS_SMEM_WCNT (LG_TS_WAVES * LG_TS_BINS * 2)
+#define LG_TS_SMEM (LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT + LG_TS_BINS * 4 + 64)
+static_assert(LG_TS_WAVES * (LG_TW_CAP * 8 + LG_TS_BINS * 2) <= LG_TS_SMEM, "the four single-wave sorts fit the workgroup sort's LDS");
+__global__ void __launch_bounds__(LG_TS_THREADS)
+lg_tile_sort(int ntiles, const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
+             int store_drop, int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LG_TS_SMEM];
+    if (counters[0] != 0u) return;                 // view aborted
+    const uint32_t nquad = ((uint32_t)ntiles + 3u) / 4u;
+    if (blockIdx.x < nquad) {
+        const uint32_t wave = threadIdx.x >> 6, tile = blockIdx.x * 4u + wave;
+        if (tile >= (uint32_t)ntiles) return;
+        unsigned char* mine = smem + wave * (LG_TW_CAP * 8 + LG_TS_BINS * 2);
+        lg_tile_sort_wave(tile, threadIdx.x & 63u, reinterpret_cast<uint64_t*>(mine), reinterpret_cast<unsigned short*>(mine + LG_TW_CAP * 8), ranges, entries,
+                          gid_bits, gid_mask, store_drop, depth_bits, tinfo);
+    } else {
+        lg_tile_sort_wg(blockIdx.x - nquad, reinterpret_cast<uint64_t*>(smem), reinterpret_cast<unsigned short (*)[LG_TS_BINS]>(smem + LG_TS_SMEM_STAGE),
+                        reinterpret_cast<uint32_t*>(smem + LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT),
+                        reinterpret_cast<uint32_t*>(smem + LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT + LG_TS_BINS * 4), ranges, entries, gid_bits, gid_mask, store_drop,
+                        depth_bits, tinfo, long_tiles);
+    }
+}
+
+// Lists beyond LG_TS_CAP: persistent grid over the tiles the workgroup path listed (none on most scenes: an empty launch).
 #define LG_TL_THREADS 1024
 #define LG_TL_WAVES (LG_TL_THREADS / 64)
 #define LG_TL_ITEMS 8
