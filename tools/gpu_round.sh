@@ -29,6 +29,7 @@ run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scene heavy --long-tiles se
 run --n-gaussians 3000000 --mode fwdbwd --steps 50 --scale 0.0045 --no-literal
 run --n-gaussians 6000000 --width 3840 --height 2160 --mode fwdbwd --steps 20 --no-literal
 timeout -s KILL 300 python tools/vq_bench.py 2>&1 | tail -4
+timeout -s KILL 420 python tools/gpu_fuzz.py 150 2>&1 | tail -2 | cut -c1-300
 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
