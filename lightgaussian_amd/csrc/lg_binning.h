@@ -395,6 +395,7 @@ lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bi
 // share LDS with the staging buffer (keys are in registers while they are ranked).
 #define LG_TS_DIGIT 9
 #define LG_TS_BINS (1 << LG_TS_DIGIT)
+#define LG_TS_RUN 8u                                       // longest run of equal upper bits the wave path finishes by insertion
 #define LG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // bits [shift, shift + popc(dmask)) of the FULL depth pattern (minus bias) of a list entry; an all-ones key (padding) has all-ones digits
@@ -452,7 +453,15 @@ __device__ __forceinline__ void lg_tile_sort_wave(uint32_t tile, uint32_t lane, 
         key[k] = ((uint32_t)k < items && idx < n) ? list[idx] : ~0ull;        // padding sorts behind everything (and stays there: stable)
     }
     const int width = lg_ts_width(depth_bits);
-    for (int shift = 0; shift < depth_bits; shift += width) {
+    // The LOWEST digit is not radix-sorted: after the passes over the upper digits the list is ordered on depth >> width, entries
+    // that agree there form runs (one pair per tile on a scene of random depths: the upper digits resolve 2^-14 relative), and a
+    // run of up to LG_TS_RUN entries is put in order by its first lane with a few compare-exchanges in LDS -- a third of the
+    // kernel for the price of two LDS reads per entry.  A longer run (coplanar splats) sends the wave through all digits
+    // instead: stable passes over what the first attempt left still end in (depth, id).  Needs every depth bit in the key.
+    const bool finish = store_drop == 0 && depth_bits > width;
+    for (int attempt = 0; attempt < 2; attempt++) {
+    const int first = (finish && attempt == 0) ? width : 0;
+    for (int shift = first; shift < depth_bits; shift += width) {
         const uint32_t dmask = (1u << min(width, depth_bits - shift)) - 1u;
         {   // clear the lane masks (4 KB) and the counters (1 KB): 16-byte stores
             uint4* z = reinterpret_cast<uint4*>(stage);
@@ -492,10 +501,48 @@ __device__ __forceinline__ void lg_tile_sort_wave(uint32_t tile, uint32_t lane, 
             if ((uint32_t)k < items) key[k] = stage[(uint32_t)k * 64u + lane];
         LG_WAVE_SYNC();
     }
+    if (first == 0) break;                         // every digit went through the passes
+    // ---- runs of equal upper bits: found from the neighbours in LDS, ordered by their first lane ----
+    const int up = gid_bits + width;               // key >> up = tile | depth >> width
+    uint32_t starts = 0;                           // bit k: my entry of item k opens a run of at least two
 #pragma unroll
     for (int k = 0; k < LG_TW_ITEMS; k++) {
         const uint32_t idx = (uint32_t)k * 64u + lane;
-        if ((uint32_t)k < items && idx < n) list[idx] = key[k];
+        if ((uint32_t)k < items && idx + 1u < n) {
+            const uint64_t me = key[k] >> up;
+            const bool opens = idx == 0u || (stage[idx - 1u] >> up) != me;
+            if (opens && (stage[idx + 1u] >> up) == me) starts |= 1u << k;
+        }
+    }
+    LG_WAVE_SYNC();
+    bool too_long = false;
+    while (starts) {                               // (divergent: few lanes own a run at all)
+        const uint32_t k = (uint32_t)__builtin_ctz(starts);
+        starts &= starts - 1u;
+        const uint32_t idx = k * 64u + lane;
+        const uint64_t me = stage[idx] >> up;
+        uint32_t e = idx + 2u;
+        while (e < n && e - idx <= LG_TS_RUN && (stage[e] >> up) == me) e++;     // (a neighbouring run may be moving: its members all differ from `me`)
+        if (e - idx > LG_TS_RUN) { too_long = true; continue; }
+        for (uint32_t a = idx + 1u; a < e; a++) {   // insertion sort on the whole key: upper bits equal, so this is (low depth bits, id)
+            const uint64_t v = stage[a];
+            uint32_t b = a;
+            while (b > idx && stage[b - 1u] > v) { stage[b] = stage[b - 1u]; b--; }
+            if (b != a) stage[b] = v;
+        }
+    }
+    LG_WAVE_SYNC();
+    if (__ballot(too_long) == 0ull) break;
+#pragma unroll
+    for (int k = 0; k < LG_TW_ITEMS; k++)
+        if ((uint32_t)k < items) key[k] = stage[(uint32_t)k * 64u + lane];
+    LG_WAVE_SYNC();
+    }
+    // `stage` holds the list in its final order (the last pass scattered into it; the finishing step worked in place)
+#pragma unroll
+    for (int k = 0; k < LG_TW_ITEMS; k++) {
+        const uint32_t idx = (uint32_t)k * 64u + lane;
+        if ((uint32_t)k < items && idx < n) list[idx] = stage[idx];
     }
 }
 
@@ -530,6 +577,9 @@ __device__ __forceinline__ void lg_tile_sort_wg(uint32_t tile, uint64_t* stage, 
         key[k] = ((uint32_t)k < items && idx < n) ? list[idx] : ~0ull;
     }
     const int width = lg_ts_width(depth_bits);
+    // (every digit through the passes here: finishing the lowest one by run insertion as lg_tile_sort_wave does was measured on this
+    //  path -- 0.107 -> 0.110 ms on the dense scene, and 0.045 -> 0.084 ms on the heavy-tailed one, whose mid-length lists sit in
+    //  the pile and hold runs beyond LG_TS_RUN: two passes + three more)
     for (int shift = 0; shift < depth_bits; shift += width) {
         const uint32_t dmask = (1u << min(width, depth_bits - shift)) - 1u;
         {   // clear the lane masks (16 KB) and the counters (4 KB)

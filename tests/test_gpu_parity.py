@@ -577,6 +577,12 @@ def test_render_pipe_alternates_match():
                    g._features_dc.grad.cpu().numpy(), g._scaling.grad.cpu().numpy(), pkg["viewspace_points"].grad.cpu().numpy())
             assert set(pkg.keys()) == {"render", "viewspace_points", "visibility_filter", "radii"}
             assert pkg["visibility_filter"].dtype == torch.bool
+            # gaussian_renderer/__init__.py:121; the fused path reads it in place from the forward's geom buffer (K1's visibility bytes)
+            assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0) and bool(pkg["visibility_filter"].any())
+            # every view gets its own screen-space leaf (its own .grad) although the leaves share one zero buffer
+            pkg2 = render(cam, g, pipe, bg)
+            assert pkg2["viewspace_points"] is not pkg["viewspace_points"] and pkg2["viewspace_points"].grad is None
+            assert float(pkg2["viewspace_points"].abs().sum()) == 0.0 and pkg["viewspace_points"].grad is not None
             if ref is None:
                 ref = out
                 continue
