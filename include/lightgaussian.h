@@ -160,9 +160,10 @@ int lg_forward_count(const lg_view* view, const lg_gaussians* g, void* geom, voi
  *           sort's look-back gave up.  When status[0] != 0 the
  *           view was abandoned on the device (every later kernel returns at once; outputs undefined, gradients of a
  *           following lg_backward are zero) and the caller re-runs it through lg_forward -- the only host decision left.
- *   host_status: NULL, or HOST uint32[4] receiving the same four words before the call returns ("validated" mode).  The
- *           library copies them to pinned memory right behind the scan kernel and waits for that copy only after the rest
- *           of the view is enqueued: the host learns R and the abort flags synchronously -- a wrapper can fall back to
+ *   host_status: NULL, or HOST uint32[4] receiving the same four words before the call returns ("validated" mode; `status`
+ *           is not written then).  The scan kernel writes them straight into pinned host memory of the library (no copy node)
+ *           and the call waits for them only after the rest of the view is enqueued: the host learns R and the abort flags
+ *           synchronously -- a wrapper can fall back to
  *           lg_forward at once and stay a safe drop-in -- while the device goes straight from the scan into the sort and
  *           the blend (the exact forward leaves it idle for the host's wake-up + allocation + launches, ~70 us per view).
  * Backward: lg_backward(..., binning, num_rendered = max_rendered, ...) with scratch lg_backward_scratch_bytes(N, max_rendered).
