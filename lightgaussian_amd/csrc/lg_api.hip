@@ -275,20 +275,23 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "duplicate", stream);
             const int dgrid = std::max(1, std::min((nblk + 4 * LG_DUP_WAVES - 1) / (4 * LG_DUP_WAVES), LG_DUP_GRID));
             lg_duplicate<<<dgrid, LG_DUP_THREADS, 0, stream>>>(N, nblk, gx, kp.stored(), kp.store_drop, kp.gid_bits, sort_begin, sort_end, (uint32_t)cap, geo.touched,
-                                                              geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, ntiles, bin.ranges, hist);
+                                                              geo.blk_off, geo.part_prefix, geo.counters, geo.offsets, geo.tinfo, bin.keys_in, ntiles, bin.ranges, hist,
+                                                              kp.two_stage ? 0xFFFFFFFFu : 0u, bin.long_tiles);
         }
         KCHECK("lg_duplicate");
         {
             ProfScope ps(prof, "sort", stream);
             size_t tb = bin.sort_temp_bytes;
-            HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (uint32_t)cap, sort_begin, sort_end, geo.counters, true, stream));
+            // two-stage scheme: the last pass also leaves the tile ranges (no lg_tile_ranges launch)
+            HIP_TRY(lg_sort_keys(bin.sort_temp, tb, bin.keys_in, bin.entries, (uint32_t)cap, sort_begin, sort_end, geo.counters, true, stream,
+                                 LG_SORT_POLL_BUDGET, kp.two_stage ? bin.ranges : nullptr, kp.tile_shift()));
         }
         KCHECK("lg_sort_keys");
-        {
+        if (!kp.two_stage) {
             ProfScope ps(prof, "tile_ranges", stream);
             const uint32_t rgrid = (uint32_t)((cap + 255) / 256);
             lg_tile_ranges<<<rgrid, 256, 0, stream>>>(geo.counters, kp.tile_shift(), kp.gid_bits, kp.gid_mask, kp.two_stage ? 0 : kp.store_drop, kp.store_drop,
-                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges, bounded ? bounded->status : nullptr, bin.long_tiles);
+                                                      bin.entries, bin.keys_in, geo.tinfo, bin.ranges, bounded ? bounded->status : nullptr);
         }
         KCHECK("lg_tile_ranges");
         if (kp.two_stage) {
@@ -296,7 +299,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             // same launch); the few longer ones go through a persistent grid of 1024-thread workgroups (an empty launch otherwise)
             ProfScope ps(prof, "tile_sort", stream);
             lg_tile_sort<<<(ntiles + 3) / 4 + ntiles, LG_TS_THREADS, 0, stream>>>(ntiles, geo.counters, bin.ranges, bin.entries, kp.gid_bits, kp.gid_mask, kp.store_drop,
-                                                                                  kp.depth_bits, geo.tinfo, bin.long_tiles);
+                                                                                  kp.depth_bits, geo.tinfo, bin.long_tiles, bounded ? bounded->status : nullptr);
             lg_tile_sort_long<<<std::min(ntiles, LG_TL_GRID), LG_TL_THREADS, 0, stream>>>(geo.counters, bin.ranges, bin.entries, bin.keys_in, kp.gid_bits, kp.gid_mask,
                                                                                           kp.store_drop, kp.depth_bits, geo.tinfo, bin.long_tiles);
             KCHECK("lg_tile_sort");
@@ -842,7 +845,7 @@ extern "C" int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t
     uint32_t* tickets = (uint32_t*)(base + L.ticket_off);
     // n_arg = one tile beyond the orphan so that tile 1 is inside the key range; it sorts keys_in[0..n) as its own keys
     lg_onesweep_pass<<<1, LG_SORT_BLOCK, 0, stream>>>(keys_in - LG_SORT_TILE, keys_out - LG_SORT_TILE, nullptr, (uint32_t)(LG_SORT_TILE + n), 0, 8,
-                                                       (uint32_t*)(base + L.hist_off), tickets, (uint32_t*)(base + L.state_off), tickets + 15, 64u);
+                                                       (uint32_t*)(base + L.hist_off), tickets, (uint32_t*)(base + L.state_off), tickets + 15, 64u, nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_onesweep_pass launch", e);
     uint32_t h_err = 0;

@@ -144,13 +144,16 @@ lg_duplicate(int N, int nblk, int gx, int stored_depth_bits, int store_drop, int
              const uint32_t* __restrict__ touched, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ part_prefix,
              const uint32_t* __restrict__ counters,
              uint32_t* __restrict__ offsets, uint4* __restrict__ tinfo, uint64_t* __restrict__ keys,
-             int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
+             int ntiles, uint2* __restrict__ ranges, uint32_t* __restrict__ hist, uint32_t range_init, uint32_t* __restrict__ long_tiles)
 {
     __shared__ uint32_t lh[LG_SORT_MAX_PASSES * 256];
     __shared__ uint32_t s_exc[LG_DUP_WAVES][64], s_xy[LG_DUP_WAVES][64], s_w[LG_DUP_WAVES][64], s_hi[LG_DUP_WAVES][64], s_lo[LG_DUP_WAVES][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // empty tiles keep {0, 0}: cleared here (this kernel runs before the sort) instead of by a memset
-    for (int t = blockIdx.x * LG_DUP_THREADS + (int)tid; t < ntiles; t += gridDim.x * LG_DUP_THREADS) ranges[t] = make_uint2(0u, 0u);
+    // tile ranges initialised here (this kernel runs before the sort) instead of by a memset: {0, 0} when lg_tile_ranges fills
+    // them in (empty tiles keep it), {0xFFFFFFFF, 0} when the last radix pass does with atomicMin / atomicMax (two-stage sort;
+    // lg_tile_sort turns what is left of it -- empty tiles, every tile of an aborted view -- into {0, 0})
+    for (int t = blockIdx.x * LG_DUP_THREADS + (int)tid; t < ntiles; t += gridDim.x * LG_DUP_THREADS) ranges[t] = make_uint2(range_init, 0u);
+    if (blockIdx.x == 0 && tid == 0) long_tiles[0] = 0u;             // list of the tiles lg_tile_sort leaves to lg_tile_sort_long
     const int passes = (sort_end - sort_begin + 7) / 8;
     for (int i = (int)tid; i < passes * 256; i += LG_DUP_THREADS) lh[i] = 0;
     __syncthreads();
@@ -315,10 +318,9 @@ __device__ __forceinline__ void lg_wave_sort_run(uint32_t i, uint32_t e, int low
 __global__ void __launch_bounds__(256)
 lg_tile_ranges(const uint32_t* __restrict__ counters, int tile_shift, int gid_bits, uint32_t gid_mask, int finish_bits, int store_drop,
                uint64_t* entries /* the sorted keys */, uint64_t* scratch, const uint4* __restrict__ tinfo, uint2* __restrict__ ranges,
-               uint32_t* status /* lg_forward_bounded's status words, or NULL */, uint32_t* __restrict__ long_tiles /* [0] = 0: the list lg_tile_sort_mid leaves to lg_tile_sort_long */)
+               uint32_t* status /* lg_forward_bounded's status words, or NULL */)
 {
     __shared__ uint32_t s_cnt[4][256];
-    if (blockIdx.x == 0 && threadIdx.x == 0) long_tiles[0] = 0u;
     if (counters[0] != 0u) {                       // view aborted (capacity-bounded forward, or the sort's look-back gave up)
         // K2 handed the caller its copy of the abort word BEFORE the sort ran: an abort raised by the sort is added here
         if (status && blockIdx.x == 0 && threadIdx.x == 0 && (counters[0] & LG_ABORT_SORT)) {
@@ -646,19 +648,31 @@ __device__ __forceinline__ void lg_tile_sort_wg(uint32_t tile, uint64_t* stage, 
 #define LG_TS_SMEM (LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT + LG_TS_BINS * 4 + 64)
 static_assert(LG_TS_WAVES * (LG_TW_CAP * 8 + LG_TS_BINS * 2) <= LG_TS_SMEM, "the four single-wave sorts fit the workgroup sort's LDS");
 __global__ void __launch_bounds__(LG_TS_THREADS)
-lg_tile_sort(int ntiles, const uint32_t* __restrict__ counters, const uint2* __restrict__ ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
-             int store_drop, int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles)
+lg_tile_sort(int ntiles, const uint32_t* __restrict__ counters, uint2* ranges, uint64_t* entries, int gid_bits, uint32_t gid_mask,
+             int store_drop, int depth_bits, const uint4* __restrict__ tinfo, uint32_t* long_tiles, uint32_t* status)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LG_TS_SMEM];
-    if (counters[0] != 0u) return;                 // view aborted
+    const bool aborted = counters[0] != 0u;        // capacity-bounded forward gave the view up, or the sort's look-back did
     const uint32_t nquad = ((uint32_t)ntiles + 3u) / 4u;
+    if (aborted && status && blockIdx.x == 0 && threadIdx.x == 0 && (counters[0] & LG_ABORT_SORT)) {
+        // K2 handed the caller its copy of the abort word BEFORE the sort ran: an abort raised by the sort is added here
+        __hip_atomic_store(&status[0], counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (blockIdx.x < nquad) {
         const uint32_t wave = threadIdx.x >> 6, tile = blockIdx.x * 4u + wave;
         if (tile >= (uint32_t)ntiles) return;
+        // The last radix pass left {begin, end} of every tile that has entries (atomicMin / atomicMax over {0xFFFFFFFF, 0}); the
+        // blend kernels expect {0, 0} for an empty tile -- and for EVERY tile of an aborted view, whose ranges may be half-made
+        const uint2 r0 = ranges[tile];
+        if (aborted || r0.x == 0xFFFFFFFFu) {
+            if ((threadIdx.x & 63u) == 0u) ranges[tile] = make_uint2(0u, 0u);
+            return;
+        }
         unsigned char* mine = smem + wave * (LG_TW_CAP * 8 + LG_TS_BINS * 2);
         lg_tile_sort_wave(tile, threadIdx.x & 63u, reinterpret_cast<uint64_t*>(mine), reinterpret_cast<unsigned short*>(mine + LG_TW_CAP * 8), ranges, entries,
                           gid_bits, gid_mask, store_drop, depth_bits, tinfo);
     } else {
+        if (aborted) return;
         lg_tile_sort_wg(blockIdx.x - nquad, reinterpret_cast<uint64_t*>(smem), reinterpret_cast<unsigned short (*)[LG_TS_BINS]>(smem + LG_TS_SMEM_STAGE),
                         reinterpret_cast<uint32_t*>(smem + LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT),
                         reinterpret_cast<uint32_t*>(smem + LG_TS_SMEM_STAGE + LG_TS_SMEM_WCNT + LG_TS_BINS * 4), ranges, entries, gid_bits, gid_mask, store_drop,

@@ -110,7 +110,7 @@ __device__ __forceinline__ void lg_st_state(uint32_t* p, uint32_t v) { (void)__h
 __global__ void __launch_bounds__(LG_SORT_BLOCK) LG_SORT_OCC
 lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ counters, uint32_t n_arg,
                  int shift, int nbits, const uint32_t* __restrict__ hist, uint32_t* ticket, uint32_t* states, uint32_t* err,
-                 uint32_t poll_budget)
+                 uint32_t poll_budget, uint2* ranges, int range_shift)
 {
     __shared__ uint64_t stage[LG_SORT_TILE];
     __shared__ unsigned short wcnt[LG_SORT_WAVES][256];
@@ -258,7 +258,17 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
     for (uint32_t q = tid; q < tile_n; q += LG_SORT_BLOCK) {
         const uint64_t kq = stage[q];
         const uint32_t d = (uint32_t)(kq >> shift) & dmask;
-        dst[(size_t)(goff[d] + q)] = kq;
+        const uint32_t pos = goff[d] + q;
+        dst[(size_t)pos] = kq;
+        if (ranges) {
+            // LAST pass of a sort whose top field (key >> range_shift) is the rasterizer's tile id: the keys of one id are
+            // contiguous in `stage` (digit = its top bits, the passes before ordered the rest) and in the output, so the ends of
+            // each id's stretch in THIS sort tile bound its range from inside; min / max over the sort tiles give {begin, end}.
+            // ranges[] starts as {0xFFFFFFFF, 0} (lg_duplicate); ids without a key keep that (lg_tile_sort turns it into {0, 0}).
+            const uint32_t t = (uint32_t)(kq >> range_shift);
+            if (q == 0u || (uint32_t)(stage[q - 1u] >> range_shift) != t) atomicMin(&ranges[t].x, pos);
+            if (q + 1u == tile_n || (uint32_t)(stage[q + 1u] >> range_shift) != t) atomicMax(&ranges[t].y, pos + 1u);
+        }
     }
 }
 
@@ -268,8 +278,11 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
 // counters: optional device words {[0] abort flag, [3] key count} (see lg_onesweep_pass); n = capacity = upper bound of the count.
 // err: device word that receives LG_ABORT_SORT when a look-back gives up (NULL: counters[0], or -- without counters -- word 15 of
 // the ticket block, which lg_debug_sort_keys reads back).
+// ranges != NULL: the last pass also writes, per value t of key >> range_shift, {first, last + 1} output position into ranges[t]
+// (see lg_onesweep_pass; the caller initialised ranges[] to {0xFFFFFFFF, 0}).
 static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, uint32_t n, int begin_bit,
-                               int end_bit, uint32_t* counters, bool hist_ready, hipStream_t stream, uint32_t poll_budget = LG_SORT_POLL_BUDGET)
+                               int end_bit, uint32_t* counters, bool hist_ready, hipStream_t stream, uint32_t poll_budget = LG_SORT_POLL_BUDGET,
+                               uint2* ranges = nullptr, int range_shift = 0)
 {
     const LgSortLayout L = lg_sort_layout(n);
     if (temp == nullptr) { temp_bytes = L.total; return hipSuccess; }
@@ -294,7 +307,7 @@ static hipError_t lg_sort_keys(void* temp, size_t& temp_bytes, const uint64_t* k
         uint64_t* dst = to_output ? keys_out : keys_tmp;
         lg_onesweep_pass<<<L.tiles, LG_SORT_BLOCK, 0, stream>>>(src, dst, counters, n, bit, nb, hist + (size_t)p * 256, tickets + p,
                                                                  states + (size_t)p * L.tiles * 256, counters ? counters : tickets + 15,
-                                                                 poll_budget);
+                                                                 poll_budget, p == passes - 1 ? ranges : nullptr, range_shift);
         src = dst;
         to_output = !to_output;
     }
