@@ -66,7 +66,7 @@ def _screenspace_points(pc):
     and saves the add, its autograd node and the clone retain_grad() makes at the end of every backward (~25 us per step
     at 3M Gaussians)."""
     xyz = pc.get_xyz
-    if not xyz.is_cuda:
+    if not xyz.is_cuda or torch.is_inference_mode_enabled():      # (inference tensors cannot share a normal buffer's leaf machinery)
         return torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
     # Nothing ever writes this tensor (it exists for its .grad), so every view's leaf can share ONE zero buffer per device and
     # shape: detach() gives a fresh leaf -- its own .grad, its own identity in the render package -- over the same storage, and

@@ -91,6 +91,9 @@ def test_the_library_has_no_process_wide_setters_and_the_segment_length_travels_
         with pytest.raises(AttributeError):
             getattr(C.CDLL(_lib.LIB_PATH), name)
     assert [f[0] for f in _lib.lg_view._fields_][-1] == "segment_length"
+    for n in (0, 1, 63, 64, 100000):                                     # visibility bytes live inside the geom buffer (host-only query)
+        off = lib.lg_geom_visible_offset(n)
+        assert off % 16 == 0 and off + n <= lib.lg_geom_bytes(n)
     a, b = lib.lg_binning_bytes(100000, 640, 480, 0), lib.lg_binning_bytes(100000, 640, 480, 512)
     assert a == b > 0                                                   # 0 = the default of 512
     assert lib.lg_binning_bytes(100000, 640, 480, 64) > a               # more checkpoint records for shorter segments
