@@ -4,7 +4,8 @@
 //   lg_host.h        error strings, optional hipEvent profiler, scratch carving (GeomView / ImgView / BinView)
 //   lg_wave.h        wave64 primitives (DPP / permlane reductions)
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
-//   lg_binning.h     K2 lg_scan_blocks, K3 lg_duplicate<PACKED>, K5 lg_tile_ranges, lg_work_order (K2-K5 all hand-written; lg_sort.h = K4)
+//   lg_binning.h     K2 lg_scan_blocks, K3 lg_duplicate, lg_tile_sort / _long (second sort stage), lg_tile_ranges (one-stage cross-check only),
+//                    lg_work_order (K2-K5 all hand-written; lg_sort.h = K4)
 //   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
@@ -14,8 +15,8 @@
 //
 // Pipeline of one view:
 //   K1 project + EWA + SH->RGB + exact footprint culling  ->  K2 scan of instance counts, blocking read of R
-//   K3 packed keys tile|depth|id  ->  K4 stable keys-only radix sort (lowest depth bits skipped when that saves a pass)
-//   K5 tile ranges + completion of the skipped bits; the sorted keys ARE the per-tile lists (no id / slot arrays)
+//   K3 packed keys tile|depth|id  ->  K4 stable keys-only radix passes over the TILE bits (the last one also leaves the tile ranges)
+//   K5b every tile's list ordered by depth inside LDS (lg_tile_sort); the sorted keys ARE the per-tile lists (no id / slot arrays)
 //   K6 front-to-back blend (4 autonomous waves per 16x16 tile, LDS queue, select-based pair step, ballot early exit)
 //   K7 back-to-front replay (1 wave per tile, longest lists first, 4 px/lane, packed permlane reduction, one 48-B
 //      gradient row per instance at its pre-sort slot, recomputed from the Gaussian's tile rectangle)
@@ -126,8 +127,8 @@ static KeyPlan make_key_plan(int ntiles, int N, uint32_t dmax_bits, uint32_t fla
     const uint32_t dspan = dmax_bits > LG_DEPTH_BIAS ? dmax_bits - LG_DEPTH_BIAS : 0u;
     k.depth_bits = bits_for(dspan + 1u) > 0 ? bits_for(dspan + 1u) : 1;
     // The three fields must fit 64 bits.  When they do not (6 M Gaussians at 3840x2160: 15 + 27 + 23 = 65; 20 M at 1080p; ...)
-    // the lowest depth bits are left out of the key and lg_tile_ranges completes the order from the full depth pattern in the
-    // binning record (tinfo) -- r2 fell back to a (tile << 32 | depth, id) pair sort through hipCUB there, without the bounded
+    // the lowest depth bits are left out of the key and the tile sort reads the full depth pattern from the binning record
+    // (tinfo) -- r2 fell back to a (tile << 32 | depth, id) pair sort through hipCUB there, without the bounded
     // forward, the graph and the fused histograms.  At least one depth bit is always stored (tile <= 32 bits, id <= 29).
     const int avail = (flags & LG_FLAG_NARROW_KEY) ? LG_NARROW_KEY_BITS : 64;
     k.store_drop = std::max(0, std::min(k.depth_bits - 1, k.tile_bits + k.depth_bits + k.gid_bits - avail));

@@ -1,4 +1,4 @@
-// lg_binning.h -- binning kernels: K2 lg_scan_blocks (+ depth maximum), K3 lg_duplicate (packed keys, fused digit histograms), K5 lg_tile_ranges, lg_tile_sort (second sort stage), lg_work_order
+// lg_binning.h -- binning kernels: K2 lg_scan_blocks (+ depth maximum), K3 lg_duplicate (packed keys, fused digit histograms), lg_tile_ranges (one-stage cross-check), lg_tile_sort (second sort stage), lg_work_order
 // Part of liblightgaussian_hip.so (single translation unit: lg_api.hip includes the lg_*.h kernel headers).
 #pragma once
 
@@ -121,7 +121,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
 // Key format: tile | (depth bits - bias) >> store_drop | Gaussian id in one u64, sorted keys-only on the tile + depth bits: the
 // stable radix sort keeps the emission (= id) order among equal depths, and the id rides along for free.  store_drop > 0 only
 // when tile + depth + id exceed 64 bits (6 M Gaussians at 4K, 20 M at 1080p, ...): the lowest depth bits are then not STORED
-// at all and lg_tile_ranges finishes the order from the full depth in tinfo (no pair format, no library sort: the former
+// at all and the tile sort takes the full depth from tinfo (no pair format, no library sort: the former
 // (tile << 32 | depth, id) fallback through hipCUB is gone).
 //
 // Wave-cooperative expansion: a wave takes the 64 Gaussians of one K1 workgroup, scans their instance counts, and then
@@ -237,9 +237,8 @@ __device__ __forceinline__ uint32_t lg_slot_of(const uint4 r, int tx, int ty)
 }
 
 // K5: tile ranges from the sorted keys (one pass over 8 B per instance; nothing else is materialised -- the blend kernels read
-// the sorted keys themselves).  In the default TWO-STAGE sort (round 3) the radix passes before this kernel covered the tile bits
-// only and lg_tile_sort (below) orders every list by depth afterwards: finish_bits = 0, this kernel only finds the boundaries.
-// With LG_FLAG_SORT_ALL_BITS the radix passes covered every STORED depth bit too (the round-2 scheme, kept as the independent
+// the sorted keys themselves).  NOT launched in the default TWO-STAGE sort (round 3): there the last radix pass leaves the ranges
+// itself (lg_onesweep_pass) and lg_tile_sort (below) orders every list by depth.  With LG_FLAG_SORT_ALL_BITS the radix passes covered every STORED depth bit too (the round-2 scheme, kept as the independent
 // cross-check of the tests) and this kernel completes the order on the bits a key beyond 64 bits does not store:
 //   store_drop  low depth bits that are not in the key at all (tile + depth + id beyond 64 bits): read from tinfo[id].z
 // Entries that agree on the stored bits form runs that are still in emission (= id) order; ordering a run stably on its

@@ -167,7 +167,7 @@ struct BinView {
     uint2* work;                    // [tiles + R / S + 1] work items {tile, segment} of the backward blend, longest first
     uint2* par_work;                // [tiles + R / S + 1] the items of the tiles whose list goes through the parallel long-tile forward
     uint32_t* par_arrived;          // [tiles] per long tile: segments that finished pass 1 (the last one to arrive scans the tile)
-    uint32_t* long_tiles;           // [1 + tiles] second sort stage: [0] = number of lists beyond a workgroup's LDS capacity, then their tiles (lg_tile_sort_mid -> _long)
+    uint32_t* long_tiles;           // [1 + tiles] second sort stage: [0] = number of lists beyond a workgroup's LDS capacity, then their tiles (lg_tile_sort -> lg_tile_sort_long)
     uint32_t* meta;                 // [16] 0 = number of work items, 1 = longest list of the view, 2 = S, 3 = par_min of the view
                                     //      (0 = none), 4 = number of par_work items (all written by lg_work_order_body)
     float4* ckpt;                   // [2 (R / S + 1)][256] checkpoint records {T, segment colour} of long tiles (lg_blend_fwd)

@@ -212,7 +212,7 @@ lg_onesweep_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, c
             // loads, all in flight) cuts that to ~sqrt(2 * tiles / window).  States are consumed nearest-first; a zero
             // (unpublished) state is re-polled alone.  (The TOTAL number of polls of a thread is bounded: a predecessor
             // always publishes -- ticket order -- so the bound is never reached; if it ever is, the would-be hang of the device
-            // becomes a REPORTED failure: bit LG_ABORT_SORT of *err (the view's abort word counters[0]: lg_tile_ranges and the
+            // becomes a REPORTED failure: bit LG_ABORT_SORT of *err (the view's abort word counters[0]: lg_tile_sort / lg_tile_ranges and the
             // blend kernels then leave the view empty, the status words / LG_FLAG_DEBUG / lg_view_status() surface LG_ERR_DEVICE).)
             uint32_t budget = poll_budget;
             int64_t b = (int64_t)tile - 1;
