@@ -66,9 +66,6 @@ __device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1,
 {
     const float x1 = x0 + 7.0f, y1 = y0 + 7.0f;
     const bool box = (r0.x + r2.y >= x0) && (r0.x - r2.y <= x1) && (r0.y + r2.z >= y0) && (r0.y - r2.z <= y1);
-#ifdef LG_BOX_ONLY
-    return box;
-#else
     const float ha = r0.z, nb = r0.w, hc = r1.x;
     const float dxe = fminf(fmaxf(r0.x, x0), x1) - r0.x, dye = fminf(fmaxf(r0.y, y0), y1) - r0.y;   // nearest point of the block
     // on the vertical line through the nearest point: dy* = -nb dxe / (2 hc), clamped to the block
@@ -78,7 +75,6 @@ __device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1,
     const float p2 = (ha * dx2 + nb * dye) * dx2 + hc * dye * dye;
     const bool reach = fmaxf(p1, p2) >= -e.tau;
     return box && (reach || !e.cull);
-#endif
 }
 
 // Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
@@ -92,25 +88,15 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
     // hardware-exp variant: no clamp of the exponent -- lanes with power > 0 are rejected by `ok` below whatever exp returned
     // (inf -> alpha 0.99, NaN compares false), and the guard's rare branch clamps for itself
-#ifdef LG_ABL_NO_EXP              // ablation (timing only, wrong results): no transcendental
-    const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : (power * 0.01f + 0.5f);
-#else
     const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : __expf(power);
-#endif
     float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
-#ifndef LG_ABL_NO_GUARD           // ablation (timing only): no threshold guard
     if (!EXACT) alpha = guard_alpha(alpha, b.y, power);
-#endif
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     const float test_T = T * (1.0f - alpha);
     const bool sat = ok && (test_T < LG_T_MIN);
-#ifdef LG_K6_TWO_CMP
-    const bool contrib = ok && !sat;
-#else
     // (ok && !sat) written as an exclusive-or of the two lane masks: hipcc evaluated `!sat` with a second v_cmp (ngt) next to the
     // one for `sat` -- compares cost 1.7x an fma on gfx950 -- where one s_xor of the masks does
     const bool contrib = ok != sat;
-#endif
     // one select on the weight instead of three on the colours: fmaf(rgb, 0, C) == C bit for bit (finite rgb)
     if (COLOR) {   // significance-only passes (LG_FLAG_SKIP_COLOR) carry no colour at all
         const float w = contrib ? alpha * T : 0.0f;
@@ -568,34 +554,6 @@ __device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* 
 #define LG_RED_FLOATS (9 * LG_RED_STRIDE)
 __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float* red, float* dst, uint32_t lane)
 {
-#ifdef LG_K7_QUAD_PREREDUCE
-    // (A/B switch, round 3) quads are summed in registers first (2 DPP adds per value), so only every 4th lane writes and the
-    // read side is ONE ds_read_b128 per lane: a fifth of the LDS bytes for 6 more VALU instructions
-    float qsum[9];
-#pragma unroll
-    for (int v = 0; v < 9; v++) {
-        float t = dpp_add<0xB1, 0xf>(p[v]);
-        qsum[v] = dpp_add<0x4E, 0xf>(t);
-    }
-    if ((lane & 3u) == 0u) {
-#pragma unroll
-        for (int v = 0; v < 9; v++) red[v * 20 + (int)(lane >> 2)] = qsum[v];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        const uint32_t r = min(lane >> 2, 8u), q = lane & 3u;
-        const float4 x = *reinterpret_cast<const float4*>(red + r * 20 + q * 4u);
-        float s = (x.x + x.y) + (x.z + x.w);
-        s = dpp_add<0xB1, 0xf>(s);
-        s = dpp_add<0x4E, 0xf>(s);
-        if (q == 0u && lane < 36u) dst[lane >> 2] = s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return;
-#endif
 #pragma unroll
     for (int v = 0; v < 9; v++) red[v * LG_RED_STRIDE + (int)lane] = p[v];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -604,19 +562,8 @@ __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float*
     const uint32_t r = min(lane >> 2, 8u), q = lane & 3u;
     const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
     const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-#ifdef LG_K7_PK_REDUCE
-    // (A/B switch, round 3) the 16 -> 1 sum as a tree of packed adds (v_pk_add_f32: 7 + 1 instructions instead of 15; a packed
-    // add costs 1.44x a plain one on gfx950, so ~37 instead of 45 issue cycles).  Another association than the default below.
-    typedef float lg_f2 __attribute__((ext_vector_type(2)));
-    const lg_f2 a0 = lg_f2{x0.x, x0.y} + lg_f2{x0.z, x0.w}, a1 = lg_f2{x1.x, x1.y} + lg_f2{x1.z, x1.w};
-    const lg_f2 a2 = lg_f2{x2.x, x2.y} + lg_f2{x2.z, x2.w}, a3 = lg_f2{x3.x, x3.y} + lg_f2{x3.z, x3.w};
-    const lg_f2 b0 = a0 + a1, b1 = a2 + a3;
-    const lg_f2 c0 = b0 + b1;
-    float s = c0.x + c0.y;
-#else
     float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
               (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
-#endif
     s = dpp_add<0xB1, 0xf>(s);                      // quad_perm [1,0,3,2]
     s = dpp_add<0x4E, 0xf>(s);                      // quad_perm [2,3,0,1]: every lane of the quad holds the row total
     if (q == 0u && lane < 36u) dst[lane >> 2] = s;
@@ -675,47 +622,6 @@ __device__ __forceinline__ bool bwd_pair(const float4& a, const float4& b, const
     return false;
 }
 
-#ifdef LG_K7_VEC_COLOUR   // A/B switch (round 3): the colour recurrence as a 3-vector per pixel, as shipped in round 2
-__device__ __forceinline__ bool bwd_pair_fast_vec(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf,
-                                              float& T, float Tfb, float g0, float g1, float g2, float& a0, float& a1,
-                                              float& a2, float (&p)[9])
-{
-#pragma clang fp contract(fast)
-    const float dx = a.x - pxf, dy = a.y - pyf;
-    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
-    const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
-    const float op = b.y;
-    const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
-    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
-    // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (a + 0 * d = a)
-    // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
-    const float am = ok ? alpha : 0.0f;
-    const float inv = __builtin_amdgcn_rcpf(1.0f - am);
-    const float Tn = T * inv;
-    // a0..a2 = colour accumulated behind this entry (eager form of the published last_alpha/last_color recurrence);
-    // d = c - a serves both dL/dalpha and the update a += am * d
-    const float d0 = b.z - a0, d1 = b.w - a1, d2 = c.x - a2;
-    const float dL_dalpha = (d0 * g0 + d1 * g1 + d2 * g2) * Tn - Tfb * inv;      // Tfb = T_final * (bg . dL/dC), per pixel
-    const float t = ok ? G * dL_dalpha : 0.0f;
-    // no select on T: on invalid lanes am = 0, and v_rcp_f32(1.0f) is exactly 1.0f on gfx950, so Tn == T bit for bit there
-    // (measured: gradients bit-identical to the version with `T = ok ? Tn : T`, K7 1.2 % faster; tools/gpu_r2_e.sh)
-    T = Tn;
-    a0 = am * d0 + a0;
-    a1 = am * d1 + a1;
-    a2 = am * d2 + a2;
-    const float dch = am * Tn;
-    const float tdx = t * dx, tdy = t * dy;
-    p[0] += tdx;
-    p[1] += tdy;
-    p[2] += tdx * dx;
-    p[3] += tdx * dy;
-    p[4] += tdy * dy;
-    p[5] += t;
-    p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
-    return ok;
-}
-#endif
-
 // Training-path variant (hardware exp / rcp, contraction allowed), written BRANCH-FREE: every lane runs
 // the whole sequence and invalid lanes are neutralised by zeroing t and the colour weight and by
 // selecting the old state.  (A branchy version makes hipcc copy the 9 accumulators at every nesting level.  A scalar
@@ -727,26 +633,14 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
 #pragma clang fp contract(fast)
     const float dx = a.x - pxf, dy = a.y - pyf;
     const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy); // identical to the forward's expression
-#ifdef LG_ABL_NO_EXP              // ablation (timing only): no transcendental
-    const float G = power * 0.01f + 0.5f;
-#else
     const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
-#endif
     const float op = b.y;
-#ifdef LG_ABL_NO_GUARD            // ablation (timing only): no threshold guard
-    const float alpha = fminf(LG_ALPHA_MAX, op * G);
-#else
     const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
-#endif
     const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
     // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (S + 0 * d = S)
     // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
     const float am = ok ? alpha : 0.0f;
-#ifdef LG_ABL_NO_RCP              // ablation (timing only): no reciprocal
-    const float inv = 1.0f + am;
-#else
     const float inv = __builtin_amdgcn_rcpf(1.0f - am);
-#endif
     const float Tn = T * inv;
     // S = (colour accumulated behind this entry) . dL/dC of this pixel, carried as ONE scalar (round 3): the published
     // recurrence a <- a + alpha (c - a) is linear, so its projection on g obeys S <- S + alpha (c.g - S), and dL/dalpha only
@@ -786,9 +680,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     __shared__ float4 q0[LG_Q], q1[LG_Q];
     __shared__ float q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
-#ifndef LG_K7_DPP_REDUCE
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
-#endif
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
     if (meta[2] != (uint32_t)S) return;           // another segment length than the forward's (see lg_preprocess_bwd)
     const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
@@ -907,14 +799,6 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                         }
                     }
                 } else {
-#ifdef LG_K7_VEC_COLOUR
-#pragma unroll
-                    for (int v = 0; v < 9; v++) p[v] = 0.0f;
-#pragma unroll
-                    for (int s = 0; s < 4; s++)
-                        if (m & (1u << s))
-                            cmask |= __ballot(bwd_pair_fast_vec(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], a0[s], a1[s], a2[s], p));
-#else
                     // (round 3, measured and rejected: dispatching on the lowest hit sub-block so that it ASSIGNS the nine partial
                     //  sums -- no zeroing: 9 v_mov per entry whenever sub-block 0 is not hit -- made the kernel 7 % SLOWER,
                     //  0.695 -> 0.745 ms: ten copies of the pair step instead of four, 92 VGPRs)
@@ -924,16 +808,9 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                     for (int s = 0; s < 4; s++)
                         if (m & (1u << s))
                             cmask |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
-#endif
                 }
                 if (cmask == 0) continue;
-#if defined(LG_ABL_NO_REDUCE)     // ablation (timing only, wrong results): no wave reduction
-                if (lane < 9) stage[j * 9 + lane] = p[0] + p[1] + p[2] + p[3] + p[4] + p[5] + p[6] + p[7] + p[8];
-#elif defined(LG_K7_DPP_REDUCE)
-                wave_reduce9_to_lds(p, stage + j * 9, lane);
-#else
                 wave_reduce9_via_lds(p, red, stage + j * 9, lane);
-#endif
                 hitmask |= 1ull << j;
             }
             __builtin_amdgcn_wave_barrier();
@@ -959,12 +836,8 @@ __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __r
     __shared__ float dst[9];
     float p[9];
     for (int c = 0; c < 9; c++) p[c] = in[threadIdx.x * 9 + c];
-#ifdef LG_K7_DPP_REDUCE
-    wave_reduce9_to_lds(p, dst, threadIdx.x);
-#else
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
     wave_reduce9_via_lds(p, red, dst, threadIdx.x);
-#endif
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
     if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x];

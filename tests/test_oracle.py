@@ -59,6 +59,57 @@ def test_oracle_f64_matches_autograd_twin(cfg):
         assert err < 1e-4, f"{name}: {err}"   # 1e-7 regulariser of the published cov2D backward <= 1.3e-5
 
 
+@pytest.mark.parametrize("D", [0, 1, 2])
+def test_stored_degree_three_with_a_lower_active_degree_matches_the_autograd_twin(D):
+    """shs [N,16,3] with sh_degree D < 3 (scene/gaussian_model.py:46,125-127: every run starts at active_sh_degree 0 over 16 stored
+    coefficients): colours use the first (D + 1)^2 coefficients only, the gradient of the rest is exactly zero."""
+    t = _dense_case(50, 40, 36, seed=10 + D, deg=3)
+    t["sh_degree"] = D
+    N, W, H = 50, 40, 36
+    assert t["shs"].shape[1] == 16
+    means2D = torch.zeros(N, 3, dtype=torch.float64, requires_grad=True)
+    color, radii, count = torch_dense.render_dense(means2D=means2D, **t)
+    gimg = torch.randn(3, H, W, dtype=torch.float64, generator=torch.Generator().manual_seed(8))
+    (color * gimg).sum().backward()
+    kwn = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in t.items()}
+    f = oracle.forward(count=True, dtype=np.float64, **kwn)
+    gr = oracle.backward(f, gimg.numpy())
+    assert np.abs(f.color - color.detach().numpy()).max() < 1e-12
+    cut = dict(kwn); cut["shs"] = np.ascontiguousarray(kwn["shs"][:, : (D + 1) ** 2])
+    assert np.array_equal(oracle.forward(dtype=np.float64, **cut).color, f.color)
+    ref = t["shs"].grad.numpy()
+    assert np.abs(gr["shs"] - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.count_nonzero(gr["shs"][:, (D + 1) ** 2:]) == 0 and np.count_nonzero(ref[:, (D + 1) ** 2:]) == 0
+    for name in ("means3D", "opacities", "scales", "rotations"):
+        r = t[name].grad.numpy().reshape(gr[name].shape)
+        assert np.abs(gr[name] - r).max() <= 1e-4 * np.abs(r).max(), name
+
+
+@pytest.mark.parametrize("mod", [0.5, 2.0])
+def test_scale_modifier_convention_of_the_oracle(mod):
+    """scale_modifier (gaussian_renderer/__init__.py:58; GUI path prune_finetune.py:111-115): the forward uses mod * scale; the
+    published backward returns dL/d(mod * scale) as "the scale gradient" -- the modifier's own factor is omitted [RECALLED-UPSTREAM,
+    SURVEY App. A].  Pinned here: rendering (scales, mod) equals rendering (mod * scales, 1) bit for bit (mod a power of two), every
+    gradient included, and the latter's gradients equal the independent autograd derivation."""
+    g = syn.make_gaussians(300, seed=3, extent=(1.5, 1.0, 1.5), log_scale_mean=math.log(0.06), opacity_mean=0.0)
+    cam = syn.orbit_camera(1, 7, 64, 48, radius=4.0)
+    kw = common.scene_kwargs(g, cam, 64, 48, bg=(0.1, 0.2, 0.3))
+    gimg = np.random.RandomState(1).randn(3, 48, 64)
+    for dt in (np.float32, np.float64):
+        a = oracle.forward(dtype=dt, scale_modifier=mod, **kw)
+        kb = dict(kw); kb["scales"] = (kw["scales"].astype(dt) * dt(mod))
+        b = oracle.forward(dtype=dt, **kb)
+        assert np.array_equal(a.color, b.color) and np.array_equal(a.radii, b.radii)
+        ga, gb = oracle.backward(a, gimg), oracle.backward(b, gimg)
+        for name in ("means2D", "means3D", "opacities", "shs", "scales", "rotations"):
+            assert np.array_equal(ga[name], gb[name]), name
+    # ... and the precomputed-covariance input ignores the modifier altogether
+    kc = dict(kw); del kc["scales"], kc["rotations"]
+    kc["cov3D_precomp"] = oracle.cov3d(kw["scales"], kw["rotations"], mod)
+    assert np.array_equal(oracle.forward(scale_modifier=mod, **kc).color, oracle.forward(scale_modifier=1.0, **kc).color)
+    assert np.array_equal(oracle.forward(**kc).color, oracle.forward(scale_modifier=mod, **kw).color)
+
+
 def test_oracle_f32_close_to_f64_and_counts_equal():
     g = syn.make_gaussians(5000, seed=11, log_scale_mean=math.log(0.02))
     cam = syn.orbit_camera(2, 9, 200, 150)

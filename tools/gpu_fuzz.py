@@ -34,15 +34,19 @@ for t in range(trials):
         continue
     N = int(rs.choice([1, 2, 7, 64, 65, 300, 2000, 9000]))
     W, H = int(rs.choice([1, 5, 16, 17, 33, 100, 257])), int(rs.choice([1, 3, 16, 31, 64, 130]))
-    deg = int(rs.randint(0, 4))
+    stored = int(rs.randint(0, 4))
+    deg = int(rs.randint(0, stored + 1))                 # r4: active degree <= stored degree (scene/gaussian_model.py:125-127)
+    mod = float(rs.choice([1.0, 1.0, 0.5, 2.0, np.exp(rs.uniform(np.log(0.3), np.log(3.0)))]))   # r4: scaling_modifier (gaussian_renderer/__init__.py:58)
     scale = float(np.exp(rs.uniform(np.log(0.002), np.log(0.8))))
-    g = syn.make_gaussians(N, sh_degree=deg, seed=1000 + t, log_scale_mean=math.log(scale), opacity_mean=float(rs.uniform(-4, 3)),
+    g = syn.make_gaussians(N, sh_degree=stored, seed=1000 + t, log_scale_mean=math.log(scale), opacity_mean=float(rs.uniform(-4, 3)),
                            extent=(float(rs.uniform(0.3, 3)), float(rs.uniform(0.3, 2)), float(rs.uniform(0.3, 3))), log_scale_std=float(rs.uniform(0.1, 1.2)))
     cam = syn.orbit_camera(int(rs.randint(0, 8)), 8, W, H, radius=float(rs.uniform(2.5, 7)))
     if rs.rand() < 0.25:   # depth slab in front of camera 0
         cam = syn.orbit_camera(0, 8, W, H, radius=5.0)
         g._xyz[:, 2] = float(rs.choice([0.0, 1e-6, 1e-4])) * torch.randn(N)
-    kw = common.scene_kwargs(g, cam, W, H, deg=deg, bg=tuple(rs.rand(3).astype(np.float32)), as_torch=True)
+    kw = common.scene_kwargs(g, cam, W, H, deg=stored, bg=tuple(rs.rand(3).astype(np.float32)), as_torch=True)
+    kw["sh_degree"] = deg
+    kw["scale_modifier"] = mod
     npk = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}
     ref = oracle.forward(count=True, **npk)
     out = gpu_common.hip_forward_backward(kw, count=True)
@@ -54,6 +58,7 @@ for t in range(trials):
     ok = not why
     gimg = rs.randn(3, H, W).astype(np.float32)
     fast = gpu_common.hip_forward_backward(kw, grad_image=gimg)
+    if deg < stored and np.count_nonzero(fast["grads"]["shs"][:, (deg + 1) ** 2:]): why.append("dL_dshs beyond the active degree not zero")
     if np.abs(fast["color"] - ref.color).max() > 1e-5: why.append(f"fast-image({np.abs(fast['color'] - ref.color).max():.2e})")
     # gradients: against the float64 oracle, tolerance 1e-4 widened to 3x the error the float32 ORACLE itself has against
     # float64 on these inputs (the T/(1-alpha) replay of the published algorithm amplifies rounding), as tests/ do
@@ -73,7 +78,7 @@ for t in range(trials):
         print("   canonical arithmetic:", {n: f"{gpu_common.rel_err(v.reshape(g64[n].shape), g64[n]):.2e}" for n, v in ex["grads"].items() if n in g64 and g64[n] is not None})
     if why:
         bad += 1
-        print(f"MISMATCH trial {t}: N={N} {W}x{H} deg={deg} scale={scale:.4f}: {', '.join(why)}")
+        print(f"MISMATCH trial {t}: N={N} {W}x{H} deg={deg}/{stored} mod={mod:.3f} scale={scale:.4f}: {', '.join(why)}")
 # ---- phase 2: getters inside the kernels (render_fused, LG_FLAG_RAW_PARAMS) against the literal torch getter pattern ----
 from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused  # noqa: E402
 dev = torch.device("cuda:0")
@@ -84,6 +89,8 @@ for t in range(n2):
     N = int(rs.choice([1, 63, 64, 65, 500, 4099, 20000]))
     W, H = int(rs.choice([16, 33, 100, 257])), int(rs.choice([16, 31, 64, 130]))
     deg = int(rs.randint(0, 4))
+    act = int(rs.randint(0, deg + 1))
+    mod2 = float(rs.choice([1.0, 1.0, 0.5, 2.0, 1.37]))
     mk = lambda: syn.make_gaussians(N, sh_degree=deg, seed=5000 + t, log_scale_mean=math.log(float(np.exp(rs_scale))), opacity_mean=op_mean,
                                     extent=(2, 1.2, 2)).to(dev).requires_grad_(True)
     rs_scale, op_mean = rs.uniform(np.log(0.005), np.log(0.3)), float(rs.uniform(-3, 2))
@@ -93,7 +100,8 @@ for t in range(n2):
     res = []
     for fn in (_render_unfused, render_fused):
         g = mk()
-        pkg = fn(cam, g, syn.PipelineParams(), bg)
+        g.active_sh_degree = act
+        pkg = fn(cam, g, syn.PipelineParams(), bg, mod2)
         (pkg["render"] * gimg).sum().backward()
         res.append((pkg["render"].detach(), pkg["radii"], [getattr(g, n).grad for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")]))
     (ia, ra, ga), (ib, rb, gb) = res
@@ -109,7 +117,7 @@ for t in range(n2):
         if y is None or not torch.isfinite(y).all() or e > 2e-4: why.append(f"grad:{n}({e:.2e})")
     if why:
         bad2 += 1
-        print(f"FUSED MISMATCH trial {t}: N={N} {W}x{H} deg={deg}: {', '.join(why)}")
+        print(f"FUSED MISMATCH trial {t}: N={N} {W}x{H} deg={act}/{deg} mod={mod2}: {', '.join(why)}")
 print(f"fuzz: {trials} trials, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches")
 bad += bad2
 sys.exit(1 if bad else 0)
