@@ -12,9 +12,14 @@ forward) -> L1 loss vs a ground-truth image -> backward to the raw GaussianModel
 `--mode fwd` times render() only; `--mode count` times the significance pass of config C4
 (prune_list_sharded: count_render per view, getters evaluated once, RCCL reduction at the end).
 
-Multi-GPU: one process per GPU, Gaussians replicated, cameras sharded (rank r renders views
-r, r+N, ...): weak scaling, no data-path collective in fwd/fwdbwd; `count` ends with the RCCL
-count all-reduce + ordered score exchange of lightgaussian_amd.prune.
+Multi-GPU: one process per GPU over RCCL, Gaussians replicated, cameras sharded (rank r renders views
+r, r+N, ...): weak scaling.  fwdbwd at N > 1 is a DATA-PARALLEL step: every rank renders its own
+camera, and the six gradient tensors are averaged over the ranks before the next step
+(parallel.allreduce_gradients_visible: visibility flags MAX-reduced, then ONE packed sum all-reduce of
+the rows some rank saw) -- `value` includes that exchange, `data_parallel` splits it out.  The same
+line carries the C4 significance pass (200 cameras / N per rank, RCCL integer all-reduce + ordered
+score exchange, prune mask compared with the single-rank mask).  `--mode fwd` has no collective (a
+forward-only render has nothing to exchange); `--mode count` times the C4 pass itself.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel, algorithmic bytes / measured (hipEvent) launch time vs 8 TB/s
@@ -48,8 +53,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["fwdbwd", "fwd", "count", "distill"], default="fwdbwd")
     ap.add_argument("--no-distill-overlap", action="store_true", help="--mode distill: teacher and student forwards in sequence on one stream")
-    ap.add_argument("--dense-allreduce", action="store_true", help="--mode distill, N > 1: all-reduce the dense gradient tensors (1.4 GB at C5) instead of "
+    ap.add_argument("--dense-allreduce", action="store_true", help="fwdbwd / distill, N > 1: all-reduce the dense gradient tensors (0.7 GB at C3, 1.4 GB at C5) instead of "
                     "only the rows some rank's camera saw (parallel.allreduce_gradients_visible, the default)")
+    ap.add_argument("--replicas", action="store_true", help="fwdbwd, N > 1: no gradient exchange (N independent replicas, the round-3 behaviour); for comparison only")
+    ap.add_argument("--force-collectives", action="store_true", help="run the data-parallel exchange and the C4 leg even at world size 1 (needs a process group: launch "
+                    "through torch.distributed.run --nproc-per-node 1): the RCCL code path on a 1-GPU box")
+    ap.add_argument("--no-c4-leg", action="store_true", help="fwdbwd, N > 1: skip the C4 significance pass that rides in the same JSON line")
     ap.add_argument("--n-gaussians", type=int, default=3_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -74,7 +83,7 @@ def parse():
     ap.add_argument("--sync-free", choices=["default", "off", "validated"], default="default",
                     help="rasterizer option sync_free for the timed loop: validated = bounded forward, status words read after the whole "
                          "view is enqueued (no idle device at the read-back of R); off = the exact forward with its blocking read-back")
-    ap.add_argument("--segment-length", type=int, default=0, help="rasterizer option segment_length (0 = library default 1024): per-tile lists longer than this "
+    ap.add_argument("--segment-length", type=int, default=0, help="rasterizer option segment_length (0 = library default 512): per-tile lists longer than this "
                     "are cut into independent (tile, segment) work items of the backward")
     ap.add_argument("--long-tiles", choices=["serial", "auto", "parallel"], default="auto", help="rasterizer option long_tiles (walk of outlier tile lists in the forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,6 +162,25 @@ def dry_run(args, rank, world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     digest = mask_digest(mask)
+    # the data-parallel step's exchange on synthetic gradients: rows outside a rank's visibility are zero, the visible-rows
+    # all-reduce must equal the dense one
+    from lightgaussian_amd import parallel
+    gen = torch.Generator().manual_seed(31 + rank)
+    vis = torch.rand(N, generator=gen) < 0.5
+    shapes = [(N, 3), (N, 1, 3), (N, 15, 3), (N, 1), (N, 3), (N, 4)]
+    ps = [torch.zeros(sh, requires_grad=True) for sh in shapes]
+    for q in ps:
+        q.grad = torch.randn(q.shape, generator=gen) * vis.view(-1, *([1] * (q.dim() - 1)))
+    dense = [q.grad.clone() for q in ps]
+    if world > 1:
+        for d in dense:
+            dist.all_reduce(d); d.div_(world)
+    t1 = time.perf_counter()
+    rows, _n = parallel.allreduce_gradients_visible(ps, vis) if world > 1 else (int(vis.sum()), N)
+    dp_ms = (time.perf_counter() - t1) * 1e3
+    dp_equal = all(torch.allclose(q.grad, d, rtol=1e-6, atol=1e-7) for q, d in zip(ps, dense))
+    if world > 1:
+        flag = torch.tensor([1 if dp_equal else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); dp_equal = bool(flag.item())
     if rank == 0:
         c1, i1 = lg_prune.prune_list(g, cams, pipe, bg, count_fn=fake_count)
         m1 = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, i1, 0.1))
@@ -161,7 +189,11 @@ def dry_run(args, rank, world):
                           "world_size_observed": dist.get_world_size() if world > 1 else 1, "views": V,
                           "mask_sha256": digest, "mask_equals_1gpu": bool(torch.equal(m1, mask)),
                           "counts_equal_1gpu": bool(torch.equal(c1, cnt)), "scores_bit_identical_1gpu": bool(torch.equal(i1, imp)),
-                          "pruned": int(mask.sum().item())}), flush=True)
+                          "pruned": int(mask.sum().item()),
+                          "data_parallel": {"allreduce_ms": round(dp_ms, 4), "rows_exchanged": rows, "rows_total": N, "equals_dense_allreduce": dp_equal,
+                                            "exchange": "rows seen by any rank's camera (allreduce_gradients_visible)"},
+                          "c4_pass": {"views": V, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "mask_sha256": digest,
+                                      "mask_equals_1gpu": bool(torch.equal(m1, mask))}}), flush=True)
 
 
 def algorithmic_bytes(N, V, R, P, M):
@@ -208,7 +240,7 @@ def main():
         _error_record(args, f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)", 3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or (args.force_collectives and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -248,11 +280,11 @@ def main():
     pc.requires_grad_(args.mode == "fwdbwd")
     params = [pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity]
     student = None
+    from lightgaussian_amd import parallel
     if args.mode == "distill":
         # config C5 (distill_train.py:124-146): teacher = these Gaussians at SH degree D, student = the same with
         # degree D-1 (onedownSHdegree); per step: teacher render (no grad), student render, L1 between the two, backward
         # through the student, gradients averaged across ranks (bucketed RCCL all-reduce)
-        from lightgaussian_amd import parallel
         student = parallel.make_student(pc, max(args.sh_degree - 1, 0)).requires_grad_(True)
         sparams = [student._xyz, student._features_dc, student._features_rest, student._scaling, student._rotation, student._opacity]
 
@@ -279,7 +311,20 @@ def main():
             return loss_utils.l1_dssim_loss(image, gt, 0.2)[0]
         return 0.8 * (image - gt).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt))
 
-    comm_events, comm_rows = ([] if (args.mode == "distill" and world > 1) else None), []
+    multi = world > 1 or (args.force_collectives and dist.is_initialized())
+    dp_step = multi and (args.mode == "distill" or (args.mode == "fwdbwd" and not args.replicas and args.views_in_flight == 1))
+    comm_events, comm_rows = ([] if dp_step else None), []
+
+    def exchange(plist, visible):
+        """the data-parallel step's gradient exchange, bracketed by hipEvents on this rank's stream"""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        if args.dense_allreduce:
+            parallel.allreduce_gradients(plist, force=args.force_collectives)
+        else:
+            comm_rows.append(parallel.allreduce_gradients_visible(plist, visible, force=args.force_collectives)[0])
+        ev[1].record()
+        comm_events.append(ev)
 
     def step(i, collectives=True):
         k = my_views[i % len(my_views)]
@@ -291,6 +336,8 @@ def main():
             pkg = render(cams[k], pc, pipe, bg)
             loss = photometric(pkg["render"], gts[k])
             loss.backward()
+            if collectives and dp_step:     # (the rank-0-only measurement legs below must not enter a collective)
+                exchange(params, pkg["visibility_filter"])
         elif args.mode == "fwd":
             with torch.no_grad():
                 render(cams[k], pc, pipe, bg)
@@ -299,17 +346,8 @@ def main():
                 p.grad = None
             # teacher forward on a side stream next to the student's forward (parallel.distill_step; --no-distill-overlap: in sequence)
             _l, _t, spkg = parallel.distill_step(pc, student, cams[k], pipe, bg, loss_fn=lambda a, b: (a - b).abs().mean(), overlap=not args.no_distill_overlap)
-            if collectives and world > 1:   # the rank-0-only measurement legs below must not enter a collective
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if comm_events is not None else None
-                if ev:
-                    ev[0].record()
-                if args.dense_allreduce:
-                    parallel.allreduce_gradients(sparams)
-                else:
-                    comm_rows.append(parallel.allreduce_gradients_visible(sparams, spkg["visibility_filter"])[0])
-                if ev:
-                    ev[1].record()
-                    comm_events.append(ev)
+            if collectives and dp_step:
+                exchange(sparams, spkg["visibility_filter"])
         else:
             with torch.no_grad():
                 count_render(cams[k], pc, pipe, bg)
@@ -477,17 +515,53 @@ def main():
         extra["timed_steps"] = extra["steady_state"]["steps"]
         extra["timed_seconds"] = extra["steady_state"]["seconds"]
 
+    c4 = None
+    if multi and args.mode == "fwdbwd" and not args.no_c4_leg:
+        # ---- config C4 inside the same line: the significance pass over 200 cameras, 200 / N per rank, RCCL reduction, the
+        #      reference's epilogue, and the mask against the single-rank pass (every rank takes part: collectives) ----
+        from lightgaussian_amd import prune as _prune
+        nviews = 200
+        cl = [syn.orbit_camera(k % args.views, args.views, W, H).to(dev) for k in range(nviews)]
+        st = {}
+        with torch.no_grad():
+            prune_list_sharded(pc, cl[: 4 * world], pipe, bg, force_collectives=True, streams=args.count_streams)      # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=True, streams=args.count_streams, stats=st)
+            barrier()
+            c4_s = time.perf_counter() - t0
+            mask_all = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1))
+        c4 = {"views": nviews, "views_per_rank": nviews // world, "seconds": round(c4_s, 4), "views_per_s": round(nviews / c4_s, 2),
+              "rccl_world_size": dist.get_world_size(), "exchange_ms": round(st.get("exchange_seconds", 0.0) * 1e3, 4), "collectives": st.get("collectives"),
+              "prune_ratio": 0.66, "v_pow": 0.1, "pruned": int(mask_all.sum().item()), "mask_sha256": mask_digest(mask_all),
+              "note": "prune_list_sharded over RCCL: int32 count all-reduce + round-wise ordered all_to_all of the scores + all_gather; exchange_ms = "
+                      "hipEvent time of rank 0's collectives (includes waiting for the slowest rank)"}
+        digests = [None] * world
+        dist.all_gather_object(digests, c4["mask_sha256"])
+        c4["mask_identical_on_all_ranks"] = len(set(digests)) == 1
+        if rank == 0:
+            with torch.no_grad():
+                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, local_only=True)
+                m1 = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, i1, 0.1))
+            c4.update({"mask_sha256_1gpu": mask_digest(m1), "mask_equals_1gpu": bool(torch.equal(m1, mask_all)), "counts_equal_1gpu": bool(torch.equal(c1, cnt)),
+                       "scores_bit_identical_1gpu": bool(torch.equal(i1, imp))})
+            del c1, i1, m1
+        del cnt, imp, mask_all
+        extra["c4_significance_pass"] = c4
     if comm_events:
-        # data-parallel distillation step: how much of it is the gradient exchange (hipEvents around the collectives of the last
+        # data-parallel step: how much of it is the gradient exchange (hipEvents around the collectives of the last
         # timed steps on this rank's stream; no multi-GPU timing existed before round 3's first driver run)
         torch.cuda.synchronize()
         tail = comm_events[-min(len(comm_events), args.steps):]
         ar_ms = sum(a.elapsed_time(b) for a, b in tail) / len(tail)
         extra["data_parallel"] = {"allreduce_ms": round(ar_ms, 4), "compute_ms": round(ms_per_step - ar_ms, 4),
                                   "exchange": "dense tensors (allreduce_gradients)" if args.dense_allreduce else
-                                              "rows seen by any rank's camera (allreduce_gradients_visible: bitmap OR + one packed sum)",
+                                              "rows seen by any rank's camera (allreduce_gradients_visible: visibility flags MAX-reduced + one packed sum)",
                                   "rows_exchanged_mean": (round(sum(comm_rows[-len(tail):]) / len(tail), 1) if comm_rows else None),
-                                  "rows_total": N, "bytes_per_row": 4 * (3 + 3 * ((max(args.sh_degree - 1, 0) + 1) ** 2) + 1 + 3 + 4),
+                                  "form": (None if not comm_rows else "tensors all-reduced where they lie (the union holds > 60 % of the rows: packing would cost more HBM traffic than it saves on the wire)"
+                                           if sum(comm_rows[-len(tail):]) / len(tail) > 0.6 * N else "union rows packed into one flat buffer"),
+                                  "rows_total": N, "bytes_per_row": 4 * (3 + 3 * ((((max(args.sh_degree - 1, 0)) if args.mode == "distill" else args.sh_degree) + 1) ** 2) + 1 + 3 + 4),
+                                  "rccl_world_size": dist.get_world_size(),
                                   "note": "allreduce_ms = hipEvent time around the gradient collectives of one step on rank 0 (includes waiting for the slowest rank); "
                                           "compute_ms = ms_per_step - allreduce_ms"}
     result = None
@@ -514,7 +588,8 @@ def main():
                                   "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
                        "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
-                       "parallelism": f"camera-shard x{world}"},
+                       "parallelism": (f"dp{world}: one camera per rank per step, gradients averaged over RCCL before the next step" if dp_step else
+                                       f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},
         }
         result.update(extra)
 
@@ -756,7 +831,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,34 +16,51 @@ def shard_views(num_views, world_size, rank):
     return list(range(rank, num_views, world_size))
 
 
-def allreduce_gradients(params, group=None, average=True, bucket_bytes=512 << 20):
-    """In-place all-reduce of `.grad` of every parameter that has one (same set on every rank), bucketed.
-    Returns the number of collectives issued."""
+def _reduce_op(group, average):
+    """(op, divide afterwards?): RCCL averages inside the collective (ReduceOp.AVG: no extra pass over the buffer); gloo has no AVG."""
+    if average and dist.get_backend(group) == "nccl":
+        return dist.ReduceOp.AVG, False
+    return dist.ReduceOp.SUM, average
+
+
+def allreduce_gradients(params, group=None, average=True, bucket_bytes=512 << 20, force=False, inplace_min_bytes=16 << 20):
+    """In-place all-reduce of `.grad` of every parameter that has one (same set on every rank).  Tensors of at least
+    `inplace_min_bytes` are reduced where they lie, one collective each (at 3 M Gaussians the SH gradient alone is 576 MB:
+    flattening it into a bucket would copy it twice through HBM for nothing); the small ones are flattened into buckets of
+    `bucket_bytes`.  All collectives are issued before the first wait.  Returns the number of collectives issued.
+    force: issue the collectives at world size 1 too (the real RCCL code path on a 1-GPU box: tests, bench.py --force-collectives)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return 0
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return 0
-    buckets, cur, cur_bytes = [], [], 0
+    op, divide = _reduce_op(group, average)
+    works = []
+    small = []
     for g in grads:
+        if g.numel() * g.element_size() >= inplace_min_bytes and g.is_contiguous():
+            works.append((dist.all_reduce(g, op=op, group=group, async_op=True), g, None))
+        else:
+            small.append(g)
+    buckets, cur, cur_bytes = [], [], 0
+    for g in small:
         nbytes = g.numel() * g.element_size()
         if cur and (cur_bytes + nbytes > bucket_bytes or g.dtype != cur[0].dtype):
             buckets.append(cur); cur, cur_bytes = [], 0
         cur.append(g); cur_bytes += nbytes
     if cur:
         buckets.append(cur)
-    works = []
     for b in buckets:
         flat = torch.cat([g.reshape(-1) for g in b]) if len(b) > 1 else b[0].reshape(-1)
-        works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
+        works.append((dist.all_reduce(flat, op=op, group=group, async_op=True), flat, b))
     for w, flat, b in works:
         w.wait()
-        if average:
+        if divide:
             flat.div_(world)
-        if len(b) > 1 or flat.data_ptr() != b[0].data_ptr():
+        if b is not None and (len(b) > 1 or flat.data_ptr() != b[0].data_ptr()):
             off = 0
             for g in b:
                 n = g.numel()
@@ -52,50 +69,57 @@ def allreduce_gradients(params, group=None, average=True, bucket_bytes=512 << 20
     return len(works)
 
 
-def _pack_bits(mask):
-    """bool [N] -> int32 [ceil(N / 32)] bit words (device-side, no sync)."""
-    n = mask.shape[0]
-    pad = (-n) % 32
-    m = torch.nn.functional.pad(mask.to(torch.int32), (0, pad)).view(-1, 32)
-    w = (m << torch.arange(32, device=mask.device, dtype=torch.int32)).sum(dim=1, dtype=torch.int64)     # bit 31 set => > int32 max
-    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
-
-
-def _unpack_bits(words, n):
-    bits = (words.view(-1, 1) >> torch.arange(32, device=words.device, dtype=torch.int32)) & 1
-    return bits.reshape(-1)[:n].bool()
-
-
-def allreduce_gradients_visible(params, visible, group=None, average=True):
+def allreduce_gradients_visible(params, visible, group=None, average=True, force=False, dense_above=0.6):
     """Gradient all-reduce of only the rows that can be non-zero (r2 verdict item 9).  A Gaussian that no camera of the step saw
     (radii == 0 on every rank: a third of the scene per view at C3 / C5) has an exactly zero gradient row in every tensor on
     every rank; exchanging those rows moves zeros.  Two collectives instead of one dense one:
-      1. the per-rank visibility bitmaps (N / 8 bytes: 0.75 MB at 6 M Gaussians), all-reduced with bitwise OR;
+      1. the per-rank visibility flags (one byte per Gaussian: 6 MB at 6 M Gaussians, under 1 % of the gradient bytes),
+         all-reduced with MAX -- the union.  (Bit-packed words with ReduceOp.BOR, the round-3 form, do not exist on the
+         NCCL / RCCL backend: "Cannot use ReduceOp.BOR with NCCL" -- found in round 4 by forcing the collectives at world size 1
+         on a GPU box; gloo, where the CPU tests run, accepts BOR.)
       2. ONE sum all-reduce of the union's rows of all parameters, packed into one flat buffer (few, large collectives for
          point-to-point xGMI); the reduced rows are scattered back, every other row stays what it is -- zero.
     At C5 (6 M Gaussians, 236 B of gradients each, ~2/3 visible per view) this cuts 1.4 GB per step to ~0.9 GB on 8 ranks with
     different cameras -- less when ranks look at the same part of the scene.  The result equals allreduce_gradients(params) up to
     the order in which the ring sums the ranks' contributions (identical at world size 2).
     params: tensors [N, ...] with .grad; visible: bool [N] = visibility_filter of this rank's render(s) of the step (union over a
-    camera batch).  Costs one host sync (the size of the union).  Returns (rows exchanged, N)."""
+    camera batch).  Costs one host sync (the size of the union).  Returns (rows exchanged, N).
+    PRECONDITIONS (not checked here; lightgaussian_amd.dp.exchange_gradients checks them, the second one under LG_DP_CHECK=1):
+    every rank passes the same parameters and each of them has a gradient (a parameter whose .grad is None on one rank only would
+    change that rank's flat buffer size and mismatch the collective); `visible` covers EVERY view accumulated into .grad since it
+    was last cleared, and nothing but those views contributed -- a regulariser on opacity or scale leaves non-zero values in rows
+    no view saw, and those rows are neither summed nor divided by the world size (use allreduce_gradients then).
+    dense_above: when the union holds more than this fraction of the rows, packing them costs more HBM traffic (gather + scatter
+    of nearly everything) than it saves on the wire: the tensors are then all-reduced where they lie (allreduce_gradients).  With
+    8 ranks on different cameras of an orbit the union is ~all of the scene; with 2 ranks, or cameras that look at the same
+    part of it, the packed form wins.
+    force: run the collectives at world size 1 too (tests on a 1-GPU box)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0, int(visible.shape[0])
     world = dist.get_world_size(group)
     N = int(visible.shape[0])
-    if world == 1:
+    if world == 1 and not force:
         return 0, N
-    grads = [p.grad for p in params if p.grad is not None]
+    if any(p.grad is None for p in params):
+        raise ValueError("allreduce_gradients_visible: every parameter must have a gradient (on every rank)")
+    grads = [p.grad for p in params]
     if any(g.shape[0] != N for g in grads):
         raise ValueError("allreduce_gradients_visible: every gradient must have one row per Gaussian")
-    words = _pack_bits(visible.reshape(-1).bool())
-    dist.all_reduce(words, op=dist.ReduceOp.BOR, group=group)
-    idx = torch.nonzero(_unpack_bits(words, N)).reshape(-1)             # the one host sync: sizes the packed buffer
+    union = visible.reshape(-1).to(torch.uint8)
+    if union.data_ptr() == visible.data_ptr():
+        union = union.clone()                                           # (never reduce into the caller's tensor)
+    dist.all_reduce(union, op=dist.ReduceOp.MAX, group=group)
+    idx = torch.nonzero(union).reshape(-1)                              # the one host sync: sizes the packed buffer
     k = int(idx.shape[0])
     if k == 0 or not grads:
         return 0, N
+    if k > dense_above * N:
+        allreduce_gradients(params, group=group, average=average, force=force)
+        return k, N
+    op, divide = _reduce_op(group, average)
     flat = torch.cat([g.view(N, -1).index_select(0, idx).reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
+    dist.all_reduce(flat, op=op, group=group)
+    if divide:
         flat.div_(world)
     off = 0
     for g in grads:

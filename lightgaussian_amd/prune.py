@@ -148,6 +148,9 @@ class _FrozenGetters:
 
 
 def _train_cameras(scene_or_list):
+    # (a data-parallel run shards Scene.getTrainCameras per rank, lightgaussian_amd.dp; the significance pass needs the whole list)
+    if hasattr(scene_or_list, "_lg_all_train_cameras"):
+        return scene_or_list._lg_all_train_cameras().copy()
     if hasattr(scene_or_list, "getTrainCameras"):
         return scene_or_list.getTrainCameras().copy()
     return list(scene_or_list)
@@ -294,13 +297,15 @@ def _ordered_sum(rows, out=None):
 
 
 def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False,
-                       streams=4, block=24, local_only=False, host_threads=False):
+                       streams=4, block=24, local_only=False, host_threads=False, stats=None):
     """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same Gaussians; returns the same
     (gaussian_list, imp_list) on every rank, bit-identical to the reference loop (mode="ordered") for every world size.
     Without an initialised process group (or at world size 1 unless force_collectives, or with local_only=True inside a
     distributed job) it is the single-process loop with frozen getters.
     streams: views in flight per rank (_ViewRunner: one host thread, sync-free forwards; host_threads=True = a thread per
              stream with exact forwards); 1 = the plain sequential loop.
+    stats:   optional dict; receives "exchange_seconds" (time of this rank's collectives: device events on the current stream for HIP
+             tensors, wall clock for CPU tensors), "collectives" and "world".
     block:   views per rank per round.  The pass keeps a running sum and absorbs the views round by round in the reference's
              order, so scratch memory is O(block * N) floats per rank whatever the number of views (the reference's loop is
              O(N); the first version of this function held all V score vectors, O(V * N)).
@@ -309,11 +314,43 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
     # the pass discards the images: its forwards do not read 192 B of SH per Gaussian per view (a per-call option of the
     # forwards THIS pass issues -- the process defaults are not touched, other threads render as before)
     return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, max(1, int(block)),
-                               local_only, host_threads, {"skip_color_in_count": True})
+                               local_only, host_threads, {"skip_color_in_count": True}, stats)
+
+
+class _CollectiveTimer:
+    """Brackets the collectives of one pass: hipEvents on the current stream (HIP tensors) or perf_counter (gloo tests)."""
+
+    def __init__(self, dev, stats):
+        self.dev, self.stats, self.pairs, self.wall, self.n = dev, stats, [], 0.0, 0
+
+    def __call__(self, fn, *a, **kw):
+        if self.stats is None:
+            return fn(*a, **kw)
+        self.n += 1
+        if self.dev.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        import time
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        self.wall += time.perf_counter() - t0
+        return out
+
+    def finish(self, world):
+        if self.stats is None:
+            return
+        if self.pairs:
+            torch.cuda.synchronize(self.dev)
+            self.wall += sum(a.elapsed_time(b) for a, b in self.pairs) * 1e-3
+        self.stats.update({"exchange_seconds": self.wall, "collectives": self.n, "world": world})
 
 
 def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, block, local_only, host_threads,
-                        options=None):
+                        options=None, stats=None):
     distributed = dist.is_available() and dist.is_initialized() and not local_only
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
@@ -327,7 +364,9 @@ def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_f
     dev = gaussians.get_xyz.device
     f32 = dict(dtype=torch.float32, device=dev)
     runner = _ViewRunner(gaussians, pipe, background, count_fn, N, streams, host_threads, options)
+    timed = _CollectiveTimer(dev, stats)
     if world == 1 and not (distributed and force_collectives):
+        timed.finish(1)
         if V == 0:
             raise IndexError("pop from empty list")     # what the reference's viewpoint_stack.pop() raises
         # rows[0] = running sum.  It starts at +0: 0 + s == s bit for bit (scores are sums of non-negative weights), so the
@@ -357,16 +396,18 @@ def _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_f
         # ordered: rank j receives Gaussian slice j of every view of the round, in sequence order, and folds them into row 0
         send = rows[1:1 + mine].view(mine, world, chunk).permute(1, 0, 2).contiguous().view(world * mine, chunk)
         total = sum(sizes)
-        dist.all_to_all_single(recv[1:1 + total], send, output_split_sizes=sizes, input_split_sizes=[mine] * world, group=group)
+        timed(dist.all_to_all_single, recv[1:1 + total], send, output_split_sizes=sizes, input_split_sizes=[mine] * world, group=group)
         _ordered_sum(recv[:1 + total], out=recv[0])
     count_sum = runner.count_sum()
-    dist.all_reduce(count_sum, op=dist.ReduceOp.SUM, group=group)
+    timed(dist.all_reduce, count_sum, op=dist.ReduceOp.SUM, group=group)
     if mode == "allreduce":
         score = rows[0, :N].contiguous()
-        dist.all_reduce(score, op=dist.ReduceOp.SUM, group=group)
+        timed(dist.all_reduce, score, op=dist.ReduceOp.SUM, group=group)
+        timed.finish(world)
         return count_sum, score
     gathered = torch.empty(world * chunk, **f32)
-    dist.all_gather_into_tensor(gathered, recv[0].contiguous(), group=group)
+    timed(dist.all_gather_into_tensor, gathered, recv[0].contiguous(), group=group)
+    timed.finish(world)
     return count_sum, gathered[:N].contiguous()
 
 

@@ -4,6 +4,10 @@
     python -m lightgaussian_amd.run /path/to/LightGaussian/distill_train.py ...
     python -m lightgaussian_amd.run /path/to/LightGaussian/train_densify_prune.py ...
     python -m torch.distributed.run --nproc-per-node 8 -m lightgaussian_amd.run --distributed /path/to/prune_finetune.py ...
+        (--distributed = DATA-PARALLEL training of the unmodified trainer, lightgaussian_amd/dp.py: every rank draws its cameras
+         from its own shard of the train list, gradients are averaged over the ranks in front of every optimizer.step() (rows no
+         rank saw are not exchanged), add_densification_stats / max_radii2D are reduced, prune_list is sharded by camera, ranks
+         other than 0 write under <model_path>/.rank<r>)
 
 Why a runner.  The trainers import their collaborators by name from their own directory, which Python puts first on sys.path:
     from utils.loss_utils import l1_loss, ssim                 prune_finetune.py:15, distill_train.py:15, train_densify_prune.py
@@ -38,6 +42,7 @@ import sys
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _PATCHED = []          # (owner object, attribute name, original value) in patch order
 _REPORT = {}
+_DP_RENDER = {}        # the visibility-recording render() of a data-parallel run (one object, so that patching stays idempotent)
 
 
 def _rebind_everywhere(old, new):
@@ -82,6 +87,8 @@ def _prune_list(gaussians, scene, pipe, background):
     """prune.py:133-157 prune_list(gaussians, scene, pipe, background) -> (gaussian_list, imp_list)."""
     import torch
     from . import prune as lg_prune
+    from . import dp
+    dp.assert_same_count(gaussians.get_xyz.shape[0])     # data-parallel run: the collectives below are sized by N
     with torch.no_grad():       # (the reference's first view is not detached, prune.py:137-141; nothing downstream differentiates it)
         return lg_prune.prune_list_sharded(gaussians, scene, pipe, background)
 
@@ -116,6 +123,8 @@ def _prune_gaussians(self, percent, import_score):
         lg_prune.prune_gaussians(self, percent, import_score)
     else:
         lg_prune.prune_points(self, lg_prune.prune_mask(percent, import_score))
+    from . import dp
+    dp.assert_same_count(self.get_xyz.shape[0], "Gaussians after prune_gaussians")
 
 
 class _LazyNegDist:
@@ -183,15 +192,21 @@ def _patch_vq(vq_mod):
     _REPORT["vectree.vq.gumbel_sample"] = {"old": "vectree.vq.gumbel_sample", "new": "lightgaussian_amd.run gumbel_sample -> lightgaussian_amd.vq.nearest_code"}
 
 
-def patch_reference(verbose=False):
-    """Import the reference's modules (they must be importable: run from / put on sys.path the reference checkout, with this
+def patch_reference(verbose=False, data_parallel=False):
+    """data_parallel=True (run.py --distributed): additionally hang lightgaussian_amd.dp on Scene / GaussianModel and record the
+    visibility of every render() for the gradient exchange in front of optimizer.step().
+    Import the reference's modules (they must be importable: run from / put on sys.path the reference checkout, with this
     repo on the path for the `diff_gaussian_rasterization` / `simple_knn` shims) and rebind the symbols listed in the module
     docstring.  Idempotent.  Returns a report {symbol: {"old": ..., "new": ..., "also_rebound_in": n}} (or {"skipped": why})."""
     from . import gaussian_renderer as lg_gr
     from . import loss_utils as lg_loss
     gr = _module("gaussian_renderer")
     if gr is not None:
-        _set(gr, "render", lg_gr.render, "gaussian_renderer.render")
+        render = lg_gr.render
+        if data_parallel:
+            from . import dp
+            render = _DP_RENDER.setdefault("fn", dp.wrap_render(lg_gr.render))
+        _set(gr, "render", render, "gaussian_renderer.render")
         _set(gr, "count_render", lg_gr.count_render, "gaussian_renderer.count_render")
     lu = _module("utils.loss_utils")
     if lu is not None:
@@ -207,6 +222,11 @@ def patch_reference(verbose=False):
     if gm is not None and hasattr(gm, "GaussianModel"):
         _set(gm.GaussianModel, "prune_points", _prune_points, "scene.gaussian_model.GaussianModel.prune_points")
         _set(gm.GaussianModel, "prune_gaussians", _prune_gaussians, "scene.gaussian_model.GaussianModel.prune_gaussians")
+    if data_parallel:
+        from . import dp
+        sc = _module("scene")
+        dp.install(getattr(gm, "GaussianModel", None) if gm is not None else None, getattr(sc, "Scene", None) if sc is not None else None)
+        _REPORT["data_parallel"] = {"old": "one trajectory per process", "new": "lightgaussian_amd.dp: camera shard per rank + gradient all-reduce before optimizer.step"}
     vq_mod = _module("vectree.vq")
     if vq_mod is not None and hasattr(vq_mod, "EuclideanCodebook") and not isinstance(getattr(vq_mod, "torch", None), type(None)) \
             and type(getattr(vq_mod, "torch")).__name__ != "_TorchProxy":
@@ -219,15 +239,35 @@ def patch_reference(verbose=False):
 
 def unpatch_reference():
     """Undo patch_reference() (reverse order)."""
+    from . import dp
+    dp.uninstall()
+    _DP_RENDER.clear()
     while _PATCHED:
         owner, name, old = _PATCHED.pop()
         setattr(owner, name, old)
     _REPORT.clear()
 
 
+def _redirect_model_path(argv, rank):
+    """Ranks other than 0 of a data-parallel run write their outputs (cfg_args, point clouds, checkpoints, imp_score.npz: the
+    trainers write them unconditionally) under <model_path>/.rank<r> instead of on top of rank 0's files.  -m / --model_path is
+    rewritten in the trainer's argument list; without one the reference picks a random ./output/<uuid> per process anyway
+    (prune_finetune.py prepare_output_and_logger)."""
+    if rank == 0:
+        return argv
+    out = list(argv)
+    for k, a in enumerate(out):
+        if a in ("-m", "--model_path") and k + 1 < len(out):
+            out[k + 1] = os.path.join(out[k + 1], f".rank{rank}")
+        elif a.startswith("--model_path="):
+            out[k] = "--model_path=" + os.path.join(a.split("=", 1)[1], f".rank{rank}")
+    return out
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     distributed = no_patch = verbose = False
+    backend = "nccl"
     while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
         flag = argv.pop(0)
         if flag == "--distributed":
@@ -236,6 +276,8 @@ def main(argv=None):
             no_patch = True
         elif flag == "--verbose":
             verbose = True
+        elif flag.startswith("--backend="):       # gloo: CPU tests of the launcher with a stand-in trainer (the rasterizer has no CPU path)
+            backend = flag.split("=", 1)[1]
         else:
             raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose, then the script and ITS arguments)")
     if not argv:
@@ -243,8 +285,9 @@ def main(argv=None):
     script = os.path.abspath(argv[0])
     if not os.path.exists(script):
         raise SystemExit(f"lightgaussian_amd.run: {script} does not exist")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     # what `python script.py` sets up: the script's directory first; then this repo, so that the shims resolve
-    sys.argv = [script] + argv[1:]
+    sys.argv = [script] + (_redirect_model_path(argv[1:], rank) if distributed and world > 1 else argv[1:])
     for p in (_ROOT, os.path.dirname(script)):
         if p in sys.path:
             sys.path.remove(p)
@@ -257,20 +300,32 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+        if backend == "nccl" and "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
             os.environ["HIP_VISIBLE_DEVICES"] = str(local)
             local = 0
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        if world > 1 and not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
     if not no_patch:
-        report = patch_reference(verbose=verbose)
+        # --distributed is DATA-PARALLEL training (lightgaussian_amd.dp): a camera shard per rank, the gradients averaged over the
+        # ranks in front of every optimizer.step(), prune_list sharded by camera; the ranks stay bit-identical replicas of one model
+        report = patch_reference(verbose=verbose, data_parallel=distributed)
         missing = [k for k, v in report.items() if "skipped" in v]
         if missing and verbose:
             print(f"[lightgaussian_amd.run] not patched (module not importable): {missing}", file=sys.stderr)
-    runpy.run_path(script, run_name="__main__")
+    try:
+        runpy.run_path(script, run_name="__main__")
+    finally:
+        if distributed and world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

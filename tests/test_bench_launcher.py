@@ -34,6 +34,11 @@ def test_self_launch_dry_run_prints_one_line_and_the_mask_equals_the_single_rank
     assert j["views"] == 5 * world
     assert j["mask_equals_1gpu"] and j["counts_equal_1gpu"] and j["scores_bit_identical_1gpu"]
     assert len(j["mask_sha256"]) == 64 and 0 < j["pruned"] < 4096
+    # round 4: the line of an N-rank job carries the data-parallel exchange and the C4 pass (r3 verdict: "N replicas")
+    dpj, c4 = j["data_parallel"], j["c4_pass"]
+    assert dpj["equals_dense_allreduce"] is True and dpj["rows_total"] == 4096
+    assert (0 < dpj["rows_exchanged"] <= 4096) and (world == 1 or dpj["rows_exchanged"] > 2048)      # union of `world` half-visible sets
+    assert c4["rccl_world_size"] == world and c4["mask_equals_1gpu"] is True and c4["mask_sha256"] == j["mask_sha256"]
 
 
 def test_mask_digest_is_the_same_for_every_world_size():

@@ -117,3 +117,39 @@ def test_distill_step_with_the_teacher_on_a_side_stream_equals_the_sequential_fo
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
         for n in NAMES:
             assert torch.equal(a[3][n], b[3][n]), n
+
+
+def test_visible_rows_exchange_and_the_data_parallel_optimizer_step_through_rccl():
+    """lightgaussian_amd.dp (run.py --distributed) on device tensors over RCCL (backend nccl, world size 1, force=True: the real
+    collectives): the render wrapper records the visibility, exchange_gradients takes the visible-rows path, rows outside the
+    visibility are verified to be exactly zero (check=True), and the averaged gradients equal the plain backward's (sum / 1)."""
+    from lightgaussian_amd import dp
+    g, cam, pipe, bg, gimg = _setup(N=30_000)
+    pc = _model(g)
+    (render(cam, pc, pipe, bg)["render"] * gimg).sum().backward()
+    ref = _grads(pc)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=DEV)
+    try:
+        pc2 = _model(g)
+        opt = torch.optim.Adam([{"params": [getattr(pc2, n)], "lr": 1e-3, "name": n} for n in NAMES], lr=0.0, eps=1e-15)
+        pkg = dp.wrap_render(render)(cam, pc2, pipe, bg)
+        (pkg["render"] * gimg).sum().backward()
+        nvis = int(pkg["visibility_filter"].sum())
+        info = dp.exchange_gradients(opt, check=True, force=True)
+        assert info == {"rows": nvis, "of": g.num, "mode": "visible"} and 0 < nvis < g.num
+        for n in NAMES:
+            assert torch.equal(getattr(pc2, n).grad, ref[n]), n
+        # a step whose render dp did not see: dense bucketed all-reduce
+        info = dp.exchange_gradients(opt, force=True)
+        assert info["mode"] == "dense" and info["collectives"] >= 1
+        for n in NAMES:
+            assert torch.equal(getattr(pc2, n).grad, ref[n]), n
+        # the same exchange through the function bench.py calls
+        k, n_all = parallel.allreduce_gradients_visible([getattr(pc2, n) for n in NAMES], pkg["visibility_filter"], force=True)
+        assert (k, n_all) == (nvis, g.num)
+        for n in NAMES:
+            assert torch.equal(getattr(pc2, n).grad, ref[n]), n
+        dp.assert_same_count(g.num)
+    finally:
+        dist.destroy_process_group()

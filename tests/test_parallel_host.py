@@ -120,7 +120,7 @@ def _visible_worker(rank, world, port, out_dir):
 
 
 def test_visible_rows_allreduce_equals_the_dense_one(tmp_path):
-    """allreduce_gradients_visible: OR of the visibility bitmaps, then one sum all-reduce of the union's rows only -- same
+    """allreduce_gradients_visible: MAX of the visibility flags (the union), then one sum all-reduce of the union's rows only -- same
     gradients as the dense all-reduce (rows nobody saw are exactly zero everywhere)."""
     mp.spawn(_visible_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     ks = [int(np.load(tmp_path / f"v{r}.npz")["k"]) for r in range(2)]
