@@ -40,7 +40,7 @@ static int check_args(const lg_view* v, const lg_gaussians* g)
     if (!v || !g) return fail(LG_ERR_INVALID_ARGUMENT, "null view/gaussians");
     if (g->N < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "bad sizes");
     if (v->segment_length != 0 && (v->segment_length < 64 || v->segment_length % 64 != 0))
-        return fail(LG_ERR_INVALID_ARGUMENT, "lg_view.segment_length must be 0 (default 1024) or a multiple of 64");
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_view.segment_length must be 0 (default 512) or a multiple of 64");
     if ((v->flags & LG_FLAG_LONG_SERIAL) && (v->flags & LG_FLAG_LONG_PARALLEL))
         return fail(LG_ERR_INVALID_ARGUMENT, "LG_FLAG_LONG_SERIAL and LG_FLAG_LONG_PARALLEL exclude each other");
     if (g->N == 0) return LG_OK; // nothing to validate against: empty tensors carry no pointers
@@ -687,13 +687,13 @@ extern "C" int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_di
     int key_bits = 1;
     while ((1u << key_bits) < kv.cap) key_bits++;
     for (int level = 0; level < LG_KNN_LEVELS; level++) {
-        lg_knn_cells<<<nb, 256, 0, stream>>>(P, kv.cap, level, points, kv.box, kv.keys_in, kv.vals_in);
+        lg_knn_cells<<<nb, 256, 0, stream>>>(P, kv.cap, level, points, kv.box, kv.pairs_in);
         KCHECK("lg_knn_cells");
         size_t tb = kv.sort_temp_bytes;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(kv.sort_temp, tb, kv.keys_in, kv.keys_out, kv.vals_in, kv.vals_out, P, 0, key_bits, stream));
+        HIP_TRY(lg_sort_keys(kv.sort_temp, tb, kv.pairs_in, kv.pairs_out, (uint32_t)P, 32, 32 + key_bits, nullptr, false, stream));
         HIP_TRY(hipMemsetAsync(kv.cell_start, 0, (size_t)kv.cap * 4, stream));
         HIP_TRY(hipMemsetAsync(kv.cell_end, 0, (size_t)kv.cap * 4, stream));
-        lg_knn_ranges<<<nb, 256, 0, stream>>>(P, points, kv.keys_out, kv.vals_out, kv.cell_start, kv.cell_end, kv.sorted);
+        lg_knn_ranges<<<nb, 256, 0, stream>>>(P, points, kv.pairs_out, kv.cell_start, kv.cell_end, kv.sorted);
         KCHECK("lg_knn_ranges");
         uint32_t* open_in = (level & 1) ? kv.open_a : kv.open_b;
         uint32_t* open_out = (level & 1) ? kv.open_b : kv.open_a;

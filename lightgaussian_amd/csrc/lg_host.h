@@ -3,7 +3,6 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +14,7 @@
 #include <vector>
 
 #include "../../include/lightgaussian.h"
+#include "../../include/lightgaussian_debug.h"
 #include "lg_math.h"
 
 // ------------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 // Replaces submodules/simple-knn (simple_knn.cu:185-221 SimpleKNN::knn, spatial.cu:15-27 distCUDA2), the initialiser of
 // the Gaussians' scales (scene/gaussian_model.py:152-156).  The reference sorts points along a Morton curve, boxes them
 // 1024 at a time and lets every point test EVERY box (O(P^2/1024)).  Here: a uniform grid with ~2 points per cubic cell
-// built by one radix sort of cell ids, and a ring search around the query's cell that stops as soon as the third-best
+// built by one radix sort of cell ids (lg_sort_keys: the rasterizer's own onesweep), and a ring search around the query's cell that stops as soon as the third-best
 // distance is provably final (everything unseen after ring r is at least r cell sizes away).  Points still open after
 // LG_KNN_RINGS rings (sparse regions, outliers) are retried on grids with 4x, 16x, 64x, 256x larger cells; the last
 // level searches until its rings cover the whole grid, so every point terminates with the exact answer.  No host round
@@ -13,6 +13,7 @@
 #include "lg_host.h"
 #include "lg_wave.h"
 #include "lg_prune.h" // lg_order_key
+#include "lg_sort.h"  // lg_sort_keys, lg_sort_layout
 #include <float.h>
 
 #define LG_KNN_RINGS 3      // rings searched per level before a point moves on to the next coarser grid
@@ -97,29 +98,30 @@ __device__ __forceinline__ int lg_knn_coord(const LgKnnGrid& G, float v, int a)
 }
 
 __global__ void __launch_bounds__(256)
-lg_knn_cells(int P, uint32_t cap, int level, const float* __restrict__ pts, const uint32_t* __restrict__ box, uint32_t* __restrict__ keys,
-             uint32_t* __restrict__ vals)
+lg_knn_cells(int P, uint32_t cap, int level, const float* __restrict__ pts, const uint32_t* __restrict__ box, uint64_t* __restrict__ pairs)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const LgKnnGrid G = lg_knn_grid(box, P, cap, level);
     const int cx = lg_knn_coord(G, pts[3 * (size_t)i], 0), cy = lg_knn_coord(G, pts[3 * (size_t)i + 1], 1),
               cz = lg_knn_coord(G, pts[3 * (size_t)i + 2], 2);
-    keys[i] = (uint32_t)((cz * G.g[1] + cy) * G.g[0] + cx);
-    vals[i] = (uint32_t)i;
+    // cell id | point index in ONE 64-bit key: the library's own keys-only radix sort (lg_sort_keys, lg_sort.h) orders it on the cell
+    // bits; it is stable, so the points of a cell stay in index order -- what the pair sort of round 3 (hipCUB) left
+    pairs[i] = ((uint64_t)(uint32_t)((cz * G.g[1] + cy) * G.g[0] + cx) << 32) | (uint32_t)i;
 }
 
 // after the sort: cell ranges and a cell-ordered copy of the points {x, y, z, original index}
 __global__ void __launch_bounds__(256)
-lg_knn_ranges(int P, const float* __restrict__ pts, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+lg_knn_ranges(int P, const float* __restrict__ pts, const uint64_t* __restrict__ pairs,
               uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_end, float4* __restrict__ sorted)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const uint32_t k = keys[i], id = vals[i];
+    const uint64_t kv = pairs[i];
+    const uint32_t k = (uint32_t)(kv >> 32), id = (uint32_t)kv;
     sorted[i] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
-    if (i == 0 || keys[i - 1] != k) cell_start[k] = (uint32_t)i;
-    if (i == P - 1 || keys[i + 1] != k) cell_end[k] = (uint32_t)i + 1u;
+    if (i == 0 || (uint32_t)(pairs[i - 1] >> 32) != k) cell_start[k] = (uint32_t)i;
+    if (i == P - 1 || (uint32_t)(pairs[i + 1] >> 32) != k) cell_end[k] = (uint32_t)i + 1u;
 }
 
 // simple_knn.cu:129-145 updateKBest<3>: insertion into the ascending triple
@@ -187,7 +189,7 @@ lg_knn_query(int P, uint32_t cap, int level, int max_rings, const float* __restr
 
 struct KnnView {
     uint32_t* box;        // [16]: 6 bbox keys, [8 + level] = number of points still open after that level
-    uint32_t *keys_in, *keys_out, *vals_in, *vals_out;
+    uint64_t *pairs_in, *pairs_out;   // cell id << 32 | point index, before / after the sort
     uint32_t *cell_start, *cell_end;
     float4* sorted;
     uint32_t *open_a, *open_b;
@@ -204,13 +206,11 @@ static KnnView carve_knn(void* base, int P)
     while (cap < n && cap < (1u << 24)) cap <<= 1;      // cells <= next power of two of P (>= 1 point per 2 cells on average)
     v.cap = cap;
     v.box = (uint32_t*)take(64);
-    v.keys_in = (uint32_t*)take(n * 4); v.keys_out = (uint32_t*)take(n * 4);
-    v.vals_in = (uint32_t*)take(n * 4); v.vals_out = (uint32_t*)take(n * 4);
+    v.pairs_in = (uint64_t*)take(n * 8); v.pairs_out = (uint64_t*)take(n * 8);
     v.cell_start = (uint32_t*)take((size_t)cap * 4); v.cell_end = (uint32_t*)take((size_t)cap * 4);
     v.sorted = (float4*)take(n * 16);
     v.open_a = (uint32_t*)take(n * 4); v.open_b = (uint32_t*)take(n * 4);
-    size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
+    const size_t tb = lg_sort_layout(n).total;          // the library's own onesweep (lg_sort.h): no library sort is linked any more
     v.sort_temp_bytes = tb; v.sort_temp = take(tb);
     v.total = off;
     return v;

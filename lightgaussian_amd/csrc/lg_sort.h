@@ -45,7 +45,7 @@
 #endif
 static_assert(LG_SORT_BLOCK >= 256 && LG_SORT_BLOCK % 64 == 0, "one thread per digit needs >= 256 threads");
 static_assert(LG_SORT_ITEMS * 64 < 65536 && LG_SORT_TILE < 65536, "16-bit LDS counters");
-static_assert(LG_SORT_ITEMS >= 2, "the digit lane masks (waves x 256 x 8 B) live in the staging buffer (waves x items x 64 x 8 B)");
+static_assert(LG_SORT_ITEMS * 64 >= 256, "the digit lane masks (waves x 256 x 8 B) live in the staging buffer (waves x items x 64 x 8 B)");
 
 // temp-storage layout: [hist 8 x 256 u32][tickets 8 u32 (64 B)][states passes x tiles x 256 u32][keys_tmp n u64]
 struct LgSortLayout {

@@ -8,6 +8,7 @@ created on the Gaussians' own device instead of the hard-coded "cuda" (identical
 required for one-process-per-GPU sharding).
 """
 import math
+import threading
 
 import torch
 
@@ -72,15 +73,21 @@ def _screenspace_points(pc):
     # shape: detach() gives a fresh leaf -- its own .grad, its own identity in the render package -- over the same storage, and
     # the 36 MB fill per render (3M Gaussians: ~8 us) happens once.
     key = (xyz.device.index, tuple(xyz.shape), xyz.dtype)
-    buf = _ZERO_POINTS.get(key)
-    if buf is None:
-        for k in [k for k in _ZERO_POINTS if k[0] == key[0]]:
-            del _ZERO_POINTS[k]                       # the model was pruned / densified: one buffer per device
-        buf = _ZERO_POINTS[key] = torch.zeros_like(xyz, requires_grad=False)
+    with _ZERO_LOCK:
+        buf = _ZERO_POINTS.pop(key, None)
+        if buf is None:
+            buf = torch.zeros_like(xyz, requires_grad=False)
+        _ZERO_POINTS[key] = buf                       # most recently used last
+        # a few shapes per process (distill_train.py renders a teacher and a student of different N in every iteration; a prune
+        # changes N): least recently used out, under the lock (backward_over_views(host_threads=True) renders from several threads)
+        while len(_ZERO_POINTS) > _ZERO_KEEP:
+            _ZERO_POINTS.pop(next(iter(_ZERO_POINTS)))
     return buf.detach().requires_grad_(True)
 
 
 _ZERO_POINTS = {}
+_ZERO_LOCK = threading.Lock()
+_ZERO_KEEP = 4
 
 
 _RAW_FIELDS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")

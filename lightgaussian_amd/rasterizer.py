@@ -253,12 +253,19 @@ class PendingBatch:
     def __len__(self):
         return len(self.items)
 
-    def resolve(self):
+    def drop_oldest(self, n):
+        """Forget the n oldest entries without looking at them."""
+        with self.lock:
+            del self.items[:n]
+
+    def resolve(self, capacity_margin=None):
         """[(tag, abandoned)] in issue order: abandoned = the view did not fit its binning capacity, or held a depth beyond
         max_depth, and must be re-rendered (its image is the background, its counts / scores / gradients are zero).  ONE host
         sync for the whole batch; the streams that issued the views must have been joined into the current stream.
-        Capacities are raised from the instance counts the device reported, so the re-render (and later views of that
-        shape) fit."""
+        Capacities are raised from the instance counts the device reported (times capacity_margin: default = the option as
+        resolved for the calling thread), so the re-render (and later views of that shape) fit.  An implausible count (>= 2^30:
+        a status word that was never written) abandons the view but does not touch the capacity."""
+        margin = float(capacity_margin if capacity_margin is not None else resolve_options()["capacity_margin"])
         with self.lock:
             pend, self.items = self.items, []
         if not pend:
@@ -277,8 +284,8 @@ class PendingBatch:
             with _CAP_LOCK:
                 if flags & 2:
                     _CAPACITY[key] = -1                # depth bound violated: this shape goes back to the exact path
-                elif (flags or key in _CAPACITY) and _CAPACITY.get(key, 0) >= 0:
-                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * _OPTIONS["capacity_margin"]) + 4096)
+                elif R < (1 << 30) and (flags or key in _CAPACITY) and _CAPACITY.get(key, 0) >= 0:
+                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(R * margin) + 4096)
         return out
 
 
@@ -302,7 +309,10 @@ def _note_pending(opts, status, key):
     if batch is None:
         batch = _PENDING
         if len(batch) >= _PENDING_CAP:
-            batch.resolve()                             # nobody polls: learn the capacities, drop the tensors
+            # nobody polls.  The oldest entries are dropped UNREAD: their status words may have been written on streams this
+            # thread never joined (reading them here would be a blocking copy of possibly uninitialised memory in the middle of a
+            # forward, and a garbage instance count would inflate the capacity of the shape)
+            batch.drop_oldest(_PENDING_CAP // 2)
     batch.add(status, key, opts.get("tag"))
 
 
@@ -315,10 +325,10 @@ def _note_count(key, R, opts=None):
 
 
 def _native_forward(lib, call, rs, count):
-    opts = call.opts
     """One forward through the C ABI.  Exact path (lg_forward / lg_forward_count: one blocking read of the instance count,
     as the reference extension) or, with option sync_free and a known capacity for this shape, lg_forward_bounded.
     Returns (color, radii, gcount, score, geom, binning, img, num_rendered)."""
+    opts = call.opts
     dev, N = call.dev, call.N
     H, W = int(rs.image_height), int(rs.image_width)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -481,6 +491,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
         ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, binning, img)
         # visibility_filter (= radii > 0, gaussian_renderer/__init__.py:121) read in place: K1 leaves it as bytes in the geom buffer
+        # READ-ONLY view into `geom`, which is also saved for the backward: it keeps that buffer (~70 B per Gaussian) alive for as long
+        # as the caller holds visibility_filter (the trainers drop it at the end of the iteration), and an in-place write to it makes
+        # autograd refuse the backward ("modified by an inplace operation") -- loud, not silent.  A clone would be one more launch
+        # (~5 us) in a step whose launch gaps are already 7 % of it; callers that keep the mask use .clone() (lightgaussian_amd.dp does).
         off = lib.lg_geom_visible_offset(call.N)
         visible = geom[off:off + call.N].view(torch.bool)
         ctx.mark_non_differentiable(radii, visible)

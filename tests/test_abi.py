@@ -11,10 +11,13 @@ import common
 from lightgaussian_amd import _lib
 
 HDR = os.path.join(common.ROOT, "include", "lightgaussian.h")
+HDR_DEBUG = os.path.join(common.ROOT, "include", "lightgaussian_debug.h")     # diagnostics for tests/ and tools/: not the drop-in ABI
 
 
-def _declared_functions():
-    src = open(HDR).read()
+def _declared_functions(hdr=None):
+    if hdr is None:
+        return sorted(set(_declared_functions(HDR)) | set(_declared_functions(HDR_DEBUG)))
+    src = open(hdr).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"^\s*(?:int|size_t|void|const char\*)\s+\*?(lg_[a-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
@@ -26,6 +29,9 @@ def test_header_declares_expected_entry_points():
                  "lg_backward_scratch_bytes", "lg_score_from_count", "lg_last_error", "lg_abi_version"):
         assert must in names
     assert set(names) == set(_lib.EXPORTS), (sorted(set(names) ^ set(_lib.EXPORTS)))
+    # the drop-in header holds no diagnostics, the debug header nothing else (r3 verdict: eight lg_debug_* in the public ABI)
+    assert not [n for n in _declared_functions(HDR) if n.startswith("lg_debug_")]
+    assert all(n.startswith("lg_debug_") for n in _declared_functions(HDR_DEBUG)) and len(_declared_functions(HDR_DEBUG)) == 7
 
 
 def test_library_built_loads_and_exports_every_declared_symbol():
