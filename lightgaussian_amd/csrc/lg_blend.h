@@ -28,6 +28,9 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad)
 }
 
 #define LG_Q 64 // LDS queue depth per wave = one batch
+#ifndef LG_K6_QUARTER
+#define LG_K6_QUARTER 1   // K6: every 16-lane row walks the entries of its own 4 x 4 pixel block (0: one list per 8 x 8 block, rounds 1-3)
+#endif
 
 // Threshold guard of the hardware-exp variants.  alpha >= 1/255 is a discontinuity of the algorithm: a pair
 // that flips in or out changes its pixel by up to T/255.  v_exp_f32 and the canonical lg_exp differ by a few 1e-7
@@ -43,6 +46,9 @@ __device__ __forceinline__ float guard_alpha(float alpha, float opacity, float p
     }
     return alpha;
 }
+// (round 4, measured and rejected: the guard folded into the threshold test -- two compares against the ends of the doubtful band
+//  instead of subtract + |.| compare + threshold compare.  One VALU instruction less per pair (K7 417 -> 403 M, K6 209 -> 203 M per
+//  launch) but one scalar mask operation more, and the scalar unit is the busier one: K6 0.308 -> 0.313 ms, K7 unchanged.)
 
 // Does the 8 x 8 pixel block [x0, x0 + 7] x [y0, y0 + 7] hold a pixel the splat can reach (alpha >= 1/255)?
 // First the axis-aligned box of the alpha >= 1/255 ellipse (hx, hy from lg_project; inf = culling off), then the ellipse
@@ -62,9 +68,11 @@ __device__ __forceinline__ LgReach lg_reach(const float4& r0, const float4& r1, 
     e.r2hc = __builtin_amdgcn_rcpf(2.0f * r1.x);
     return e;
 }
-__device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1, const float4& r2, const LgReach& e, float x0, float y0)
+// ext = last pixel offset of the (square) block: 7 for the 8 x 8 blocks of K7, 3 for the 4 x 4 blocks of K6's quarter-wave walk.
+__device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1, const float4& r2, const LgReach& e, float x0, float y0,
+                                             float ext = 7.0f)
 {
-    const float x1 = x0 + 7.0f, y1 = y0 + 7.0f;
+    const float x1 = x0 + ext, y1 = y0 + ext;
     const bool box = (r0.x + r2.y >= x0) && (r0.x - r2.y <= x1) && (r0.y + r2.z >= y0) && (r0.y - r2.z <= y1);
     const float ha = r0.z, nb = r0.w, hc = r1.x;
     const float dxe = fminf(fmaxf(r0.x, x0), x1) - r0.x, dye = fminf(fmaxf(r0.y, y0), y1) - r0.y;   // nearest point of the block
@@ -120,7 +128,12 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              uint2* __restrict__ work, uint32_t* __restrict__ meta, uint2* __restrict__ par_work, const uint32_t* __restrict__ counters,
              int long_mode, uint32_t* __restrict__ par_arrived)
 {
-    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    __shared__ float4 q0[4][LG_Q + 1], q1[4][LG_Q + 1], q2[4][LG_Q + 1];    // slot LG_Q: the record padded queue positions point at
+#if LG_K6_QUARTER
+    __shared__ uint8_t qi[4][4][LG_Q];                    // [wave][16-lane row][position] -> record slot of that row's next entry
+    __shared__ uint32_t cacc[COUNT ? 4 : 1][COUNT ? LG_Q + 1 : 1];       // hits of (wave, record slot) in the current batch
+    __shared__ float facc[FSCORE ? 4 : 1][FSCORE ? LG_Q + 1 : 1];
+#endif
     // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
     // view's own numbers (counters[3] = its instance count), evaluated identically by every workgroup
     const uint32_t par_min = lg_par_min(long_mode, S, counters[3], ntiles);
@@ -138,11 +151,18 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     const uint32_t lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
+#if LG_K6_QUARTER
+    // quarter-wave walk: the 16-lane row `row` of the wave owns the 4 x 4 pixel block (row & 1, row >> 1) of the wave's 8 x 8 block
+    const uint32_t row = lane >> 4, rl = lane & 15u;
+    const int pxi = wx0 + (int)((row & 1u) * 4u + (rl & 3u)), pyi = wy0 + (int)((row >> 1) * 4u + (rl >> 2));
+#else
     const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
+#endif
     const bool inside = pxi < W && pyi < H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
     const uint2 range = ranges[tile];
+    const uint32_t pix_in_tile = (uint32_t)(pyi - ty * LG_TILE) * 16u + (uint32_t)(pxi - tx * LG_TILE);   // checkpoint slot of this pixel
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -151,6 +171,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // {T there, colour accumulated INSIDE the segment (absolute weights alpha T: a sum of non-negative terms, no
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
     // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
+#if LG_K6_QUARTER
+    if (lane == 0) { q0[wave][LG_Q] = make_float4(0, 0, 0, 0); q1[wave][LG_Q] = make_float4(0, 0, 0, 0); q2[wave][LG_Q] = make_float4(0, 0, 0, 0); }
+    if (COUNT) { cacc[wave][lane] = 0u; if (lane == 0) cacc[wave][LG_Q] = 0u; }
+    if (FSCORE) { facc[wave][lane] = 0.0f; if (lane == 0) facc[wave][LG_Q] = 0.0f; }
+#endif
     const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
     // lists longer than par_min (when set): their segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below)
     if (longt && par_min != 0u && (range.y - range.x) > par_min) return;
@@ -161,7 +186,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         float Cs0 = 0.0f, Cs1 = 0.0f, Cs2 = 0.0f;
         uint32_t seg = 0;
         float4* ck = nullptr;
-        if (LONG) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + (((uint32_t)(wave >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(wave & 1) * 8u + (lane & 7u));
+        if (LONG) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix_in_tile;
         // (a software pipeline over the batches -- records of batch k + 1 and list entries of batch k + 2 requested before batch
         // k is blended -- was measured: 0.311 -> 0.320 ms on the uniform scene, 1.356 -> 1.329 ms on the heavy one.  The walk of a
         // long tile is an arithmetic chain, not a latency chain: ~64 pair evaluations per batch on a lone wave.)
@@ -171,6 +196,92 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 seg++; Cs0 = Cs1 = Cs2 = 0.0f;
             }
             if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
+#if LG_K6_QUARTER
+            // ---- quarter-wave walk (round 4).  A splat of this scene covers ~52 pixels; an 8 x 8 pass spends 64 lanes on the ~16 of
+            // them that lie in the block.  Here every 16-lane row walks ITS OWN list -- the entries that reach its 4 x 4 block
+            // (6.7 such blocks per splat against 3.3 blocks of 8 x 8: half the lanes per splat) -- and one pass of the pair step serves
+            // four (entry, 4 x 4 block) pairs, one per row.  Lane i tests entry i against the four blocks; per block the hits are
+            // ballot-compacted into a byte queue of record slots (slot = lane: the records themselves are stored once); queues
+            // shorter than the longest are padded with slot LG_Q, a record of opacity 0 that fails alpha >= 1/255 by itself.
+            // Per pixel nothing changes: it meets the entries that reach its block, in list order, with the published pair step.
+            const uint32_t idx = base + lane;
+            bool h0 = false, h1 = false, h2 = false, h3 = false;
+            float4 r0, r1, r2;
+            if (idx < range.y) {
+                const uint32_t id = (uint32_t)entries[idx] & gid_mask;
+                r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
+                const LgReach reach = lg_reach(r0, r1, r2);
+                h0 = lg_block_hit(r0, r1, r2, reach, bx0, by0, 3.0f);
+                h1 = lg_block_hit(r0, r1, r2, reach, bx0 + 4.0f, by0, 3.0f);
+                h2 = lg_block_hit(r0, r1, r2, reach, bx0, by0 + 4.0f, 3.0f);
+                h3 = lg_block_hit(r0, r1, r2, reach, bx0 + 4.0f, by0 + 4.0f, 3.0f);
+            }
+            // a row whose 16 pixels are all saturated (or outside the image) walks nothing
+            const uint64_t livem = __ballot(!done);
+            const uint64_t M0 = (livem & 0xFFFFull) ? __ballot(h0) : 0ull, M1 = (livem & 0xFFFF0000ull) ? __ballot(h1) : 0ull;
+            const uint64_t M2 = (livem & 0xFFFF00000000ull) ? __ballot(h2) : 0ull, M3 = (livem & 0xFFFF000000000000ull) ? __ballot(h3) : 0ull;
+            const uint64_t anym = (M0 | M1) | (M2 | M3);
+            if (anym == 0) continue;
+            const bool mine = (anym >> lane) & 1ull;
+            if (mine) {
+                // the record copy carries the entry's contributor index (1-based position in the tile's list) where the record has
+                // the box half-extent hx, which nothing reads after the block test
+                r2.y = __uint_as_float(idx - range.x + 1u);
+                q0[wave][lane] = r0; q1[wave][lane] = r1; q2[wave][lane] = r2;
+            }
+            const uint32_t n0 = (uint32_t)__popcll(M0), n1 = (uint32_t)__popcll(M1), n2 = (uint32_t)__popcll(M2), n3 = (uint32_t)__popcll(M3);
+            const uint32_t npass = max(max(n0, n1), max(n2, n3));
+            {
+                const uint8_t me = (uint8_t)lane, pad = (uint8_t)LG_Q;
+                if ((M0 >> lane) & 1ull) qi[wave][0][prefix_popc(M0)] = me;
+                if ((M1 >> lane) & 1ull) qi[wave][1][prefix_popc(M1)] = me;
+                if ((M2 >> lane) & 1ull) qi[wave][2][prefix_popc(M2)] = me;
+                if ((M3 >> lane) & 1ull) qi[wave][3][prefix_popc(M3)] = me;
+                if (lane < npass) {
+                    if (lane >= n0) qi[wave][0][lane] = pad;
+                    if (lane >= n1) qi[wave][1][lane] = pad;
+                    if (lane >= n2) qi[wave][2][lane] = pad;
+                    if (lane >= n3) qi[wave][3][lane] = pad;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint8_t* myq = &qi[wave][row][0];
+            for (uint32_t k = 0; k < npass; k++) {
+                const uint32_t e = myq[k];
+                const float4 a = q0[wave][e], b = q1[wave][e], c = q2[wave][e];
+                float alpha = 0.0f, Tprev = T, w = 0.0f;
+                const bool res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w);
+                if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
+                if (COUNT) {
+                    // hits of this row's entry: the 16 bits of the row in the ballot; the row's first lane adds them to the slot's
+                    // counter in LDS (a row's entries are distinct; two ROWS may hold the same entry in one pass: an LDS atomic)
+                    const uint64_t cm = __ballot(res);
+                    const uint32_t half = (row >> 1) ? (uint32_t)(cm >> 32) : (uint32_t)cm;
+                    const uint32_t cnt = (uint32_t)__popc((half >> ((row & 1u) * 16u)) & 0xFFFFu);
+                    if (rl == 0u && cnt != 0u) atomicAdd(&cacc[wave][e], cnt);
+                    if (FSCORE) {
+                        float wv = res ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
+                        wv = dpp_add<0x111, 0xf>(wv); wv = dpp_add<0x112, 0xf>(wv); wv = dpp_add<0x114, 0xf>(wv); wv = dpp_add<0x118, 0xf>(wv);
+                        if (rl == 15u && cnt != 0u) atomicAdd(&facc[wave][e], wv);     // lane 15 of the row holds the row's sum
+                    }
+                }
+            }
+            if (COUNT) {
+                // lane i owns record slot i: one global atomic per (wave, Gaussian), issued 64-wide
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    const uint32_t c = cacc[wave][lane];
+                    if (c != 0u) {
+                        const uint32_t id = __float_as_uint(r2.w) & LG_ID_MASK;
+                        atomicAdd(&count[id], (int)c);
+                        cacc[wave][lane] = 0u;
+                        if (FSCORE) { atomicAdd(&fscore[id], facc[wave][lane]); facc[wave][lane] = 0.0f; }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#else
             const uint32_t idx = base + lane;
             bool hit = false;
             float4 r0, r1, r2;
@@ -221,6 +332,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             }
             __builtin_amdgcn_wave_barrier();
         }
+#endif
         if (LONG) {
             // the current segment's record, and -- when the wave stopped early -- those of the segments it never entered
             // (nothing contributed there: T stays, colour 0), so that every record of the tile is valid for every pixel
@@ -501,58 +613,18 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
 // (tile, Gaussian) instance is reduced across lanes once, not once per 8x8 block.  Per batch of 64 list
 // entries: lane l gathers entry l and computes its 4-bit sub-block overlap mask; the wave then walks the
 // batch back to front, evaluating an entry only on the sub-blocks it overlaps (scalar branches on the
-// mask).  The 9 partials are reduced with permlane32/16 swaps + row DPP adds (8 values packed into two
-// registers: ~20 instructions instead of 54), parked in LDS, and written once per batch as 48-byte gradient
+// mask).  The 9 partials are reduced through an LDS transpose (wave_reduce9_via_lds), parked in LDS, and written once per batch as 48-byte gradient
 // rows (lane j owns entry j): part [R][12] floats (9 used) = the five pixel-offset moments | sum t | drgb (see
 // lg_rows_to_grads), addressed by the instance's pre-sort slot -- no atomics, every row written exactly once.
-typedef unsigned lg_u2v __attribute__((ext_vector_type(2)));
-
-// combine two registers into one: lower 32 lanes = 32-lane partial sums of a, upper 32 lanes = of b
-__device__ __forceinline__ float fold32(float a, float b)
-{
-    lg_u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// rows (16 lanes) of the result: (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
-__device__ __forceinline__ float fold16(float a, float b)
-{
-    lg_u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float row_sum_to_lane15(float v)
-{
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    return v;
-}
-// Sums p[0..8] over the wave and writes the 9 totals to dst[0..8] (LDS).  Which 16-lane row ends up
-// with which value is fixed by the two folds: rows of w0 = (p0, p2, p1, p3), rows of w1 = (p4, p6, p5, p7).
-__device__ __forceinline__ void wave_reduce9_to_lds(const float (&p)[9], float* dst, uint32_t lane)
-{
-    const float u0 = fold32(p[0], p[1]), u1 = fold32(p[2], p[3]), u2 = fold32(p[4], p[5]), u3 = fold32(p[6], p[7]);
-    float w0 = fold16(u0, u1), w1 = fold16(u2, u3);
-    w0 = row_sum_to_lane15(w0);
-    w1 = row_sum_to_lane15(w1);
-    const float w8 = wave_sum_to_lane63(p[8]);
-    if ((lane & 15u) == 15u) {
-        const uint32_t r = lane >> 4;
-        const uint32_t k = ((r & 1u) << 1) | (r >> 1); // row -> value index inside the group of four
-        dst[k] = w0;
-        dst[4 + k] = w1;
-    }
-    if (lane == 63u) dst[8] = w8;
-}
-
-// The same sums through LDS (K7's default).  The 9 partials of every lane go to a 9 x 64 matrix `red` (row stride 68 floats:
+// K7's wave reduction of the 9 partial sums goes through LDS (the register-only permlane / DPP fold of round 1 compiled to 36 VALU
+// instructions + hazard nops per entry).  The 9 partials of every lane go to a 9 x 64 matrix `red` (row stride 68 floats:
 // conflict-free for the dwordx4 reads below); lane 4 r + q then adds columns 16 q .. 16 q + 15 of row r (four ds_read_b128,
 // 15 adds) and two quad-DPP adds join the four quarters: 17 VALU instructions per entry instead of the 36 (+ hazard nops) of
 // the register-only fold above -- the fold was a quarter of K7's instruction stream.  The LDS operations of one wave execute
 // in order, so the reads see every lane's writes without a barrier; lanes >= 36 redo row 8 (clamped row: no exec masking).
 #define LG_RED_STRIDE 68
 #define LG_RED_FLOATS (9 * LG_RED_STRIDE)
-__device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float* red, float* dst, uint32_t lane)
+__device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float* red, float* dst, uint32_t dst_off, uint32_t lane)
 {
 #pragma unroll
     for (int v = 0; v < 9; v++) red[v * LG_RED_STRIDE + (int)lane] = p[v];
@@ -566,7 +638,9 @@ __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float*
               (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
     s = dpp_add<0xB1, 0xf>(s);                      // quad_perm [1,0,3,2]
     s = dpp_add<0x4E, 0xf>(s);                      // quad_perm [2,3,0,1]: every lane of the quad holds the row total
-    if (q == 0u && lane < 36u) dst[lane >> 2] = s;
+    // dst is VALUE-major, [9][LG_Q]: total v of entry j at dst[v * LG_Q + j].  (Entry-major, `stage + 9 j` + v, cost a 64-bit
+    // v_mad_u64_u32 per entry for j * 36 + base; here the address is a per-lane constant plus a scalar shift of j.)
+    if (q == 0u && lane < 36u) dst[(lane >> 2) * LG_Q + dst_off] = s;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                // (the next entry overwrites `red`)
 }
@@ -662,9 +736,10 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
     p[4] += tdy * dy;
     p[5] += t;
     p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
-    // the lanes that contributed, as the lane mask the compare produced (a bool OR-ed over the sub-blocks and balloted afterwards
-    // cost a v_cndmask + v_cmp per entry to rebuild the mask the scalar unit already had)
-    return __ballot(ok);
+    // the lanes that contributed.  `ok` is an AND of three lane masks, and a ballot of anything but a compare is materialised by
+    // hipcc as v_cndmask(0, 1) + v_cmp_ne -- two VALU instructions to copy a mask the scalar unit already holds (ISA of rounds
+    // 1-3).  am > 0 is the same set (alpha >= 1/255 on ok lanes, 0 elsewhere) and IS a compare: one instruction.
+    return __builtin_amdgcn_ballot_w64(am > 0.0f);
 }
 
 #ifndef LG_K7_WAVES
@@ -775,14 +850,17 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             }
             const uint64_t M0 = __ballot(hit[0]), M1 = __ballot(hit[1]), M2 = __ballot(hit[2]), M3 = __ballot(hit[3]);
             __builtin_amdgcn_wave_barrier();
+            // (round 4, measured: 3 / 4 / 5 waves per SIMD run this kernel in 0.862 / 0.724 / 0.669 ms -- it is sensitive to latency,
+            //  not only to instruction count.  Requesting the NEXT entry's record before the reduction of the current one, so that the
+            //  broadcast read is off the chain, changed nothing: 0.662-0.667 vs 0.664-0.670 ms)
             for (uint64_t any = (M0 | M1) | (M2 | M3); any != 0;) {
-                const int j = 63 - __builtin_clzll(any);               // back to front
-                any &= ~(1ull << j);
-                const uint32_t m = (uint32_t)((M0 >> j) & 1ull) | ((uint32_t)((M1 >> j) & 1ull) << 1) | ((uint32_t)((M2 >> j) & 1ull) << 2) |
-                                   ((uint32_t)((M3 >> j) & 1ull) << 3);
-                const float4 a = q0[j], b = q1[j];
-                const float4 c = make_float4(q2[j], 0.0f, 0.0f, 0.0f);
-                const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)j + 1u;
+                const int jcur = 63 - __builtin_clzll(any);            // back to front
+                any &= ~(1ull << jcur);
+                const float4 a = q0[jcur], b = q1[jcur];
+                const float4 c = make_float4(q2[jcur], 0.0f, 0.0f, 0.0f);
+                const uint32_t m = (uint32_t)((M0 >> jcur) & 1ull) | ((uint32_t)((M1 >> jcur) & 1ull) << 1) | ((uint32_t)((M2 >> jcur) & 1ull) << 2) |
+                                   ((uint32_t)((M3 >> jcur) & 1ull) << 3);
+                const uint32_t rel = (uint32_t)k * LG_Q + (uint32_t)jcur + 1u;
                 float p[9];
                 uint64_t cmask = 0;                        // lanes for which the entry contributed in any sub-block (scalar)
                 if (EXACT) {
@@ -809,19 +887,20 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                         if (m & (1u << s))
                             cmask |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
                 }
-                if (cmask == 0) continue;
-                wave_reduce9_via_lds(p, red, stage + j * 9, lane);
-                hitmask |= 1ull << j;
+                if (cmask != 0) {
+                    wave_reduce9_via_lds(p, red, stage, (uint32_t)jcur, lane);
+                    hitmask |= 1ull << jcur;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
         if (lane < nbt) {
             float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0;
             if ((hitmask >> lane) & 1ull) {
-                const float* src = stage + lane * 9;
-                o0 = make_float4(src[0], src[1], src[2], src[3]);
-                o1 = make_float4(src[4], src[5], src[6], src[7]);
-                o2 = make_float4(src[8], 0.0f, 0.0f, 0.0f);
+                const float* src = stage + lane;          // value-major: [9][LG_Q]
+                o0 = make_float4(src[0], src[LG_Q], src[2 * LG_Q], src[3 * LG_Q]);
+                o1 = make_float4(src[4 * LG_Q], src[5 * LG_Q], src[6 * LG_Q], src[7 * LG_Q]);
+                o2 = make_float4(src[8 * LG_Q], 0.0f, 0.0f, 0.0f);
             }
             float4* dst = rows + 3 * (size_t)lg_slot_of(trect, tx, ty);
             dst[0] = o0; dst[1] = o1; dst[2] = o2;
@@ -830,16 +909,16 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     }
 }
 
-// diagnostics: K7's wave reduction (wave_reduce9_via_lds, or _to_lds with -DLG_K7_DPP_REDUCE) on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
+// diagnostics: K7's wave reduction (wave_reduce9_via_lds) on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
 __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
 {
-    __shared__ float dst[9];
+    __shared__ float dst[9 * LG_Q];
     float p[9];
     for (int c = 0; c < 9; c++) p[c] = in[threadIdx.x * 9 + c];
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
-    wave_reduce9_via_lds(p, red, dst, threadIdx.x);
+    wave_reduce9_via_lds(p, red, dst, 0u, threadIdx.x);
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
-    if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x];
+    if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x * LG_Q];
 }
 
