@@ -28,9 +28,6 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles_pad)
 }
 
 #define LG_Q 64 // LDS queue depth per wave = one batch
-#ifndef LG_K6_QUARTER
-#define LG_K6_QUARTER 1   // K6: every 16-lane row walks the entries of its own 4 x 4 pixel block (0: one list per 8 x 8 block, rounds 1-3)
-#endif
 
 // Threshold guard of the hardware-exp variants.  alpha >= 1/255 is a discontinuity of the algorithm: a pair
 // that flips in or out changes its pixel by up to T/255.  v_exp_f32 and the canonical lg_exp differ by a few 1e-7
@@ -128,12 +125,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
              uint2* __restrict__ work, uint32_t* __restrict__ meta, uint2* __restrict__ par_work, const uint32_t* __restrict__ counters,
              int long_mode, uint32_t* __restrict__ par_arrived)
 {
-    __shared__ float4 q0[4][LG_Q + 1], q1[4][LG_Q + 1], q2[4][LG_Q + 1];    // slot LG_Q: the record padded queue positions point at
-#if LG_K6_QUARTER
-    __shared__ uint8_t qi[4][4][LG_Q];                    // [wave][16-lane row][position] -> record slot of that row's next entry
-    __shared__ uint32_t cacc[COUNT ? 4 : 1][COUNT ? LG_Q + 1 : 1];       // hits of (wave, record slot) in the current batch
-    __shared__ float facc[FSCORE ? 4 : 1][FSCORE ? LG_Q + 1 : 1];
-#endif
+    __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
     // view's own numbers (counters[3] = its instance count), evaluated identically by every workgroup
     const uint32_t par_min = lg_par_min(long_mode, S, counters[3], ntiles);
@@ -143,6 +135,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, par_work, par_min, par_arrived);
         return;
     }
+    // (round 4, measured and rejected -- commit 'prototype: quarter-wave K6', profiles/r04_proto_k6_quarter_wave_profile_fwdbwd.json: every
+    //  16-lane row walking the entries of its own 4 x 4 block, four (entry, block) pairs per pass.  A splat of this scene covers 52
+    //  pixels in 3.3 blocks of 8 x 8 or 6.7 blocks of 4 x 4, so the pair passes halve; but every tile-entry is then tested against 16
+    //  blocks instead of 4, the per-row queues have to be built, and the entry index is one more dependent LDS read: 209 -> 197 M VALU
+    //  instructions only, 12 -> 13.7 KB of LDS per workgroup, 0.264 -> 0.283 ms.  Counts, scores and images stayed bit-identical.)
     // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
     // already give 4 rounds of wave slots; the XCD-interleaved static map stays)
     const int tile = xcd_tile(blockIdx.x, ntiles_pad);
@@ -151,13 +148,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     const uint32_t lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int wx0 = tx * LG_TILE + (wave & 1) * 8, wy0 = ty * LG_TILE + (wave >> 1) * 8;
-#if LG_K6_QUARTER
-    // quarter-wave walk: the 16-lane row `row` of the wave owns the 4 x 4 pixel block (row & 1, row >> 1) of the wave's 8 x 8 block
-    const uint32_t row = lane >> 4, rl = lane & 15u;
-    const int pxi = wx0 + (int)((row & 1u) * 4u + (rl & 3u)), pyi = wy0 + (int)((row >> 1) * 4u + (rl >> 2));
-#else
     const int pxi = wx0 + (int)(lane & 7), pyi = wy0 + (int)(lane >> 3);
-#endif
     const bool inside = pxi < W && pyi < H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const float bx0 = (float)wx0, bx1 = (float)(wx0 + 7), by0 = (float)wy0, by1 = (float)(wy0 + 7);
@@ -171,11 +162,6 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // {T there, colour accumulated INSIDE the segment (absolute weights alpha T: a sum of non-negative terms, no
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
     // ckpt[(2 (range.x / S) + j) * 256 + pixel]; 2 floor(x / S) leaves room for ceil(n / S) records before the next long tile.
-#if LG_K6_QUARTER
-    if (lane == 0) { q0[wave][LG_Q] = make_float4(0, 0, 0, 0); q1[wave][LG_Q] = make_float4(0, 0, 0, 0); q2[wave][LG_Q] = make_float4(0, 0, 0, 0); }
-    if (COUNT) { cacc[wave][lane] = 0u; if (lane == 0) cacc[wave][LG_Q] = 0u; }
-    if (FSCORE) { facc[wave][lane] = 0.0f; if (lane == 0) facc[wave][LG_Q] = 0.0f; }
-#endif
     const bool longt = COLOR && (range.y - range.x) > (uint32_t)S;            // block-uniform
     // lists longer than par_min (when set): their segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below)
     if (longt && par_min != 0u && (range.y - range.x) > par_min) return;
@@ -196,92 +182,6 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 seg++; Cs0 = Cs1 = Cs2 = 0.0f;
             }
             if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
-#if LG_K6_QUARTER
-            // ---- quarter-wave walk (round 4).  A splat of this scene covers ~52 pixels; an 8 x 8 pass spends 64 lanes on the ~16 of
-            // them that lie in the block.  Here every 16-lane row walks ITS OWN list -- the entries that reach its 4 x 4 block
-            // (6.7 such blocks per splat against 3.3 blocks of 8 x 8: half the lanes per splat) -- and one pass of the pair step serves
-            // four (entry, 4 x 4 block) pairs, one per row.  Lane i tests entry i against the four blocks; per block the hits are
-            // ballot-compacted into a byte queue of record slots (slot = lane: the records themselves are stored once); queues
-            // shorter than the longest are padded with slot LG_Q, a record of opacity 0 that fails alpha >= 1/255 by itself.
-            // Per pixel nothing changes: it meets the entries that reach its block, in list order, with the published pair step.
-            const uint32_t idx = base + lane;
-            bool h0 = false, h1 = false, h2 = false, h3 = false;
-            float4 r0, r1, r2;
-            if (idx < range.y) {
-                const uint32_t id = (uint32_t)entries[idx] & gid_mask;
-                r0 = rec[LG_REC_F4 * (size_t)id]; r1 = rec[LG_REC_F4 * (size_t)id + 1]; r2 = rec[LG_REC_F4 * (size_t)id + 2];
-                const LgReach reach = lg_reach(r0, r1, r2);
-                h0 = lg_block_hit(r0, r1, r2, reach, bx0, by0, 3.0f);
-                h1 = lg_block_hit(r0, r1, r2, reach, bx0 + 4.0f, by0, 3.0f);
-                h2 = lg_block_hit(r0, r1, r2, reach, bx0, by0 + 4.0f, 3.0f);
-                h3 = lg_block_hit(r0, r1, r2, reach, bx0 + 4.0f, by0 + 4.0f, 3.0f);
-            }
-            // a row whose 16 pixels are all saturated (or outside the image) walks nothing
-            const uint64_t livem = __ballot(!done);
-            const uint64_t M0 = (livem & 0xFFFFull) ? __ballot(h0) : 0ull, M1 = (livem & 0xFFFF0000ull) ? __ballot(h1) : 0ull;
-            const uint64_t M2 = (livem & 0xFFFF00000000ull) ? __ballot(h2) : 0ull, M3 = (livem & 0xFFFF000000000000ull) ? __ballot(h3) : 0ull;
-            const uint64_t anym = (M0 | M1) | (M2 | M3);
-            if (anym == 0) continue;
-            const bool mine = (anym >> lane) & 1ull;
-            if (mine) {
-                // the record copy carries the entry's contributor index (1-based position in the tile's list) where the record has
-                // the box half-extent hx, which nothing reads after the block test
-                r2.y = __uint_as_float(idx - range.x + 1u);
-                q0[wave][lane] = r0; q1[wave][lane] = r1; q2[wave][lane] = r2;
-            }
-            const uint32_t n0 = (uint32_t)__popcll(M0), n1 = (uint32_t)__popcll(M1), n2 = (uint32_t)__popcll(M2), n3 = (uint32_t)__popcll(M3);
-            const uint32_t npass = max(max(n0, n1), max(n2, n3));
-            {
-                const uint8_t me = (uint8_t)lane, pad = (uint8_t)LG_Q;
-                if ((M0 >> lane) & 1ull) qi[wave][0][prefix_popc(M0)] = me;
-                if ((M1 >> lane) & 1ull) qi[wave][1][prefix_popc(M1)] = me;
-                if ((M2 >> lane) & 1ull) qi[wave][2][prefix_popc(M2)] = me;
-                if ((M3 >> lane) & 1ull) qi[wave][3][prefix_popc(M3)] = me;
-                if (lane < npass) {
-                    if (lane >= n0) qi[wave][0][lane] = pad;
-                    if (lane >= n1) qi[wave][1][lane] = pad;
-                    if (lane >= n2) qi[wave][2][lane] = pad;
-                    if (lane >= n3) qi[wave][3][lane] = pad;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint8_t* myq = &qi[wave][row][0];
-            for (uint32_t k = 0; k < npass; k++) {
-                const uint32_t e = myq[k];
-                const float4 a = q0[wave][e], b = q1[wave][e], c = q2[wave][e];
-                float alpha = 0.0f, Tprev = T, w = 0.0f;
-                const bool res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w);
-                if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
-                if (COUNT) {
-                    // hits of this row's entry: the 16 bits of the row in the ballot; the row's first lane adds them to the slot's
-                    // counter in LDS (a row's entries are distinct; two ROWS may hold the same entry in one pass: an LDS atomic)
-                    const uint64_t cm = __ballot(res);
-                    const uint32_t half = (row >> 1) ? (uint32_t)(cm >> 32) : (uint32_t)cm;
-                    const uint32_t cnt = (uint32_t)__popc((half >> ((row & 1u) * 16u)) & 0xFFFFu);
-                    if (rl == 0u && cnt != 0u) atomicAdd(&cacc[wave][e], cnt);
-                    if (FSCORE) {
-                        float wv = res ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
-                        wv = dpp_add<0x111, 0xf>(wv); wv = dpp_add<0x112, 0xf>(wv); wv = dpp_add<0x114, 0xf>(wv); wv = dpp_add<0x118, 0xf>(wv);
-                        if (rl == 15u && cnt != 0u) atomicAdd(&facc[wave][e], wv);     // lane 15 of the row holds the row's sum
-                    }
-                }
-            }
-            if (COUNT) {
-                // lane i owns record slot i: one global atomic per (wave, Gaussian), issued 64-wide
-                __builtin_amdgcn_wave_barrier();
-                if (mine) {
-                    const uint32_t c = cacc[wave][lane];
-                    if (c != 0u) {
-                        const uint32_t id = __float_as_uint(r2.w) & LG_ID_MASK;
-                        atomicAdd(&count[id], (int)c);
-                        cacc[wave][lane] = 0u;
-                        if (FSCORE) { atomicAdd(&fscore[id], facc[wave][lane]); facc[wave][lane] = 0.0f; }
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-#else
             const uint32_t idx = base + lane;
             bool hit = false;
             float4 r0, r1, r2;
@@ -332,7 +232,6 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             }
             __builtin_amdgcn_wave_barrier();
         }
-#endif
         if (LONG) {
             // the current segment's record, and -- when the wave stopped early -- those of the segments it never entered
             // (nothing contributed there: T stays, colour 0), so that every record of the tile is valid for every pixel

@@ -11,7 +11,7 @@ import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))
 k = d.get("kernels_ms", {})
 print(sys.argv[1], "value", d["value"], "ms", d["ms_per_step"], "steady", d.get("steady_state", {}).get("views_per_s"),
-      "bwd", k.get("blend_bwd"), "fwd", k.get("blend_fwd"), "batch3", d.get("camera_batch_3", {}).get("views_per_s_per_gpu"), flush=True)
+      "bwd", k.get("blend_bwd"), "fwd", k.get("blend_fwd"), "k1", k.get("preprocess"), "k9", k.get("preprocess_bwd"), "sort", k.get("sort"), "tsort", k.get("tile_sort"), "dup", k.get("duplicate"), "batch3", d.get("camera_batch_3", {}).get("views_per_s_per_gpu"), flush=True)
 PY
 done
 done
