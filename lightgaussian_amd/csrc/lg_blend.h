@@ -652,8 +652,11 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
              const float* __restrict__ dL_dpix, const float4* __restrict__ ckpt, float* __restrict__ part)
 {
     __shared__ float4 q0[LG_Q], q1[LG_Q];
-    __shared__ float q2[LG_Q];
     __shared__ float stage[LG_Q * 9];
+    // the entry's third colour channel lives in row 8 of `stage` until the entry's own totals overwrite it (its reduction runs after
+    // its last read): 256 bytes of LDS less per wave, 6800 in all (round 4: K7 0.692 -> 0.682 ms bracketed.  Six waves per SIMD on top
+    // of it -- 80 VGPRs, 24 workgroups per CU now fit -- change nothing further, 0.683: measured again, as in round 3)
+    float* const q2 = stage + 8 * LG_Q;
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
     if (meta[2] != (uint32_t)S) return;           // another segment length than the forward's (see lg_preprocess_bwd)

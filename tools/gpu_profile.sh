@@ -3,7 +3,7 @@
 #   pass 1  rocprofv3 --kernel-trace --stats            -> per-kernel launch time
 #   pass 2/3 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes: TCC slots)  -> HBM traffic
 #   pass 3-7 SQ counter sets                             -> instruction counts / busy cycles
-# summarised by tools/profile_summary.py into gpurun_out/r03_profile_<mode>.json (copy to profiles/).
+# summarised by tools/profile_summary.py into gpurun_out/r04_profile_<mode>.json (copy to profiles/).
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 MODE=${1:-fwdbwd}; shift

@@ -31,6 +31,10 @@ run --n-gaussians 6000000 --width 3840 --height 2160 --mode fwdbwd --steps 20 --
 timeout -s KILL 300 python tools/vq_bench.py 2>&1 | tail -4
 timeout -s KILL 420 python tools/gpu_fuzz.py 150 2>&1 | tail -2 | cut -c1-300
 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+# the data-parallel step and the C4 leg of `bench.py --gpus N` through RCCL at world size 1 (the collectives are real, the wire is not)
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-literal --force-collectives 2>&1 | grep "^{" | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('forced collectives:', d['value'], 'views/s', d.get('data_parallel'), d.get('c4_significance_pass'))" | cut -c1-1500
 timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
 bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
