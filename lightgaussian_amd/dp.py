@@ -154,7 +154,8 @@ def wrap_optimizer(optimizer):
     inner = optimizer.step
 
     def step(*a, **kw):
-        exchange_gradients(optimizer)
+        # (LG_DP_FORCE=1: exchange at world size 1 too -- the RCCL code path of a 1-GPU box, tests/test_gpu_dp_runner.py)
+        exchange_gradients(optimizer, force=os.environ.get("LG_DP_FORCE", "0") == "1")
         return inner(*a, **kw)
 
     optimizer.step = step

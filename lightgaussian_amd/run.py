@@ -225,7 +225,8 @@ def patch_reference(verbose=False, data_parallel=False):
     if data_parallel:
         from . import dp
         sc = _module("scene")
-        dp.install(getattr(gm, "GaussianModel", None) if gm is not None else None, getattr(sc, "Scene", None) if sc is not None else None)
+        gm_cls = (getattr(gm, "GaussianModel", None) if gm is not None else None) or (getattr(sc, "GaussianModel", None) if sc is not None else None)
+        dp.install(gm_cls, getattr(sc, "Scene", None) if sc is not None else None)
         _REPORT["data_parallel"] = {"old": "one trajectory per process", "new": "lightgaussian_amd.dp: camera shard per rank + gradient all-reduce before optimizer.step"}
     vq_mod = _module("vectree.vq")
     if vq_mod is not None and hasattr(vq_mod, "EuclideanCodebook") and not isinstance(getattr(vq_mod, "torch", None), type(None)) \
@@ -307,7 +308,9 @@ def main(argv=None):
         import torch.distributed as dist
         if backend == "nccl":
             torch.cuda.set_device(local)
-        if world > 1 and not dist.is_initialized():
+        # (under a launcher -- RANK in the environment -- the group is created at world size 1 as well: harmless, every dp hook
+        #  stays passive there unless LG_DP_FORCE=1 sends the exchange through the collectives: the RCCL path on a 1-GPU box)
+        if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             else:
@@ -322,9 +325,9 @@ def main(argv=None):
     try:
         runpy.run_path(script, run_name="__main__")
     finally:
-        if distributed and world > 1:
+        if distributed:
             import torch.distributed as dist
-            if dist.is_initialized():
+            if dist.is_available() and dist.is_initialized():
                 dist.destroy_process_group()
 
 
