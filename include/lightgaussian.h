@@ -71,6 +71,10 @@ enum {
                               process rendered before.  Images of the parallel walk agree with the serial one to float rounding
                               (regrouped transmittance products), n_contrib exactly; canonical / count forwards are always serial.
                               No counterpart in the reference (its renderCUDA walks every list serially). */
+    LG_FLAG_SAVE_SH_JACOBIAN = 2048, /* forward: this view will be differentiated -- K1 leaves d rgb / d (view direction) of every visible
+                                        Gaussian (36 bytes) in the geom buffer, and lg_backward (which finds a marker word there) does not read
+                                        the SH coefficients again: 388 MB less per view at 3 M Gaussians.  Without the flag the backward
+                                        works as before.  No effect on any result (same operations in the same order). */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc

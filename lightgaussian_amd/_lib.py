@@ -22,6 +22,7 @@ WEIGHT_ONE, WEIGHT_OPACITY, WEIGHT_ALPHA, WEIGHT_ALPHA_T = 0, 1, 2, 3
 FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_L1_ONLY = 1, 2, 4, 8, 16, 32
 FLAG_NARROW_KEY, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
+FLAG_SAVE_SH_JACOBIAN = 2048
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",

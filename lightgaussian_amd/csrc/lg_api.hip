@@ -210,7 +210,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score, \
-                                                                      k1_clear, k1_nclear)
+                                                                      k1_clear, k1_nclear, (v->flags & LG_FLAG_SAVE_SH_JACOBIAN) ? 1 : 0)
             // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
             const bool direct = !(v->flags & LG_FLAG_K1_LDS);
             const bool raw = v->flags & LG_FLAG_RAW_PARAMS;
@@ -458,13 +458,16 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
         const int per = (nblk + chunks - 1) / chunks;
         for (int first_blk = 0; first_blk < nblk; first_blk += per) {
             const int nb = std::min(per, nblk - first_blk);
-#define LAUNCH_PPB(RAWP)                                                                                                             \
-    lg_preprocess_bwd<RAWP><<<nb, LG_PP, 0, stream>>>(                                                                                \
+#define LAUNCH_PPB(RAWP, JACP)                                                                                                       \
+    lg_preprocess_bwd<RAWP, JACP><<<nb, LG_PP, 0, stream>>>(                                                                                \
         N, first_blk, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy, v->scale_modifier, v->viewmatrix, v->projmatrix, v->campos, g->means3D,  \
         g->shs, g->shs_rest, g->colors_precomp, g->opacities, g->scales, g->rotations, g->cov3D_precomp, radii, geo.rec,   \
-        geo.counters, bin.meta, (uint32_t)S, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
+        geo.counters, bin.meta, (uint32_t)S, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), geo.shjac, dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
-            if (v->flags & LG_FLAG_RAW_PARAMS) LAUNCH_PPB(true); else LAUNCH_PPB(false);
+            // (the view of a backward is the view of its forward: LG_FLAG_SAVE_SH_JACOBIAN says K1 left the SH direction Jacobians)
+            const bool jac = (v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && dL_dshs;
+            if (v->flags & LG_FLAG_RAW_PARAMS) { if (jac) LAUNCH_PPB(true, true); else LAUNCH_PPB(true, false); }
+            else { if (jac) LAUNCH_PPB(false, true); else LAUNCH_PPB(false, false); }
 #undef LAUNCH_PPB
             if (on_chunk) on_chunk(user, first_blk * LG_PP, std::min(N - first_blk * LG_PP, nb * LG_PP));
         }
@@ -475,6 +478,13 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
         HIP_TRY(hipMemcpyAsync(&h_seg, bin.meta + 2, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (h_seg != (uint32_t)S) return fail(LG_ERR_INVALID_ARGUMENT, "lg_backward: lg_view.segment_length differs from the forward's (gradients are zero)");
+        if ((v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && dL_dshs) {
+            uint32_t h_mark = 0;
+            HIP_TRY(hipMemcpyAsync(&h_mark, geo.counters + 9, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (h_mark != LG_SHJAC_MAGIC)
+                return fail(LG_ERR_INVALID_ARGUMENT, "lg_backward: the view carries LG_FLAG_SAVE_SH_JACOBIAN but its forward did not (gradients are zero)");
+        }
     }
     return LG_OK;
 }

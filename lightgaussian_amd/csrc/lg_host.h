@@ -98,6 +98,9 @@ struct GeomView {
     uint4* tinfo;       // [N]     binning record: x = tx0 | ty0<<16, y = tx1 | ty1<<16 (tight tile rect), z = depth bits
     uint32_t* touched;  // [N]  instance count per Gaussian (K1)
     uint32_t* offsets;  // [N]  inclusive scan of touched (written by K3; K9 derives the slot base from it)
+    float* shjac;       // [N][9] d rgb / d (unit view direction) of the SH expansion, written by K1 when the view carries
+                        //      LG_FLAG_SAVE_SH_JACOBIAN (a forward whose backward will follow); K9 then needs no SH coefficients.
+                        //      counters[9] = LG_SHJAC_MAGIC says the rows of this view are there
     uint8_t* visible;   // [N]  1 = radius > 0 (K1): the render package's visibility_filter, read in place through lg_geom_visible_offset()
     uint32_t* counters; // [16] per-view device words: 0 = abort flags, 1 = prefiltered violation, 2 = largest depth bit
                         //      pattern, 3 = instance count R (all written by lg_scan_blocks); 8 = arrival counter of
@@ -109,6 +112,7 @@ struct GeomView {
     size_t total;
 };
 
+#define LG_SHJAC_MAGIC 0x4A414353u
 static GeomView carve_geom(void* base, int N)
 {
     GeomView g;
@@ -122,6 +126,7 @@ static GeomView carve_geom(void* base, int N)
     g.offsets = (uint32_t*)take(n * 4);
     g.visible = (uint8_t*)take(n);
     g.counters = (uint32_t*)take(64);
+    g.shjac = (float*)take(n * 36);
     g.blk_dmax = (uint32_t*)take(((n + 63) / 64) * 4);
     g.blk_sum = (uint32_t*)take(((n + 63) / 64) * 4);
     g.blk_off = (uint32_t*)take(((n + 63) / 64) * 4);

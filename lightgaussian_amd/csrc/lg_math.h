@@ -486,3 +486,89 @@ LG_HD void lg_backward_sh(int deg, const float* sh, float px, float py, float pz
     dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
     dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 }
+
+
+// The part of lg_backward_sh that needs the SH coefficients -- d rgb_c / d (unit view direction), J[3 c + {0,1,2}] = {dRdx, dRdy, dRdz}
+// of channel c -- depends on forward-time quantities only.  K1 evaluates it next to the colours (the coefficients are in registers
+// there) and leaves 36 bytes per visible Gaussian; K9 then never reads the 12 M bytes of SH coefficients again (round 4: 388 MB per view at
+// C3).  The expressions are those of lg_backward_sh, term for term, so the values -- and the gradients -- are bit-identical.
+LG_HD void lg_sh_dir_jacobian(int deg, const float* sh, float px, float py, float pz, const float* campos, float J[9])
+{
+    float ox = px - campos[0], oy = py - campos[1], oz = pz - campos[2];
+    float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    float x = ox / len, y = oy / len, z = oz / len;
+    for (int c = 0; c < 3; c++) {
+        float dRdx = 0.0f, dRdy = 0.0f, dRdz = 0.0f;
+        if (deg > 0) {
+            dRdx = -LG_SH_C1 * sh[3 * 3 + c];
+            dRdy = -LG_SH_C1 * sh[1 * 3 + c];
+            dRdz = LG_SH_C1 * sh[2 * 3 + c];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dRdx += LG_SH_C2_0 * y * sh[4 * 3 + c] + LG_SH_C2_2 * 2.0f * -x * sh[6 * 3 + c] + LG_SH_C2_3 * z * sh[7 * 3 + c] +
+                        LG_SH_C2_4 * 2.0f * x * sh[8 * 3 + c];
+                dRdy += LG_SH_C2_0 * x * sh[4 * 3 + c] + LG_SH_C2_1 * z * sh[5 * 3 + c] + LG_SH_C2_2 * 2.0f * -y * sh[6 * 3 + c] +
+                        LG_SH_C2_4 * 2.0f * -y * sh[8 * 3 + c];
+                dRdz += LG_SH_C2_1 * y * sh[5 * 3 + c] + LG_SH_C2_2 * 2.0f * 2.0f * z * sh[6 * 3 + c] + LG_SH_C2_3 * x * sh[7 * 3 + c];
+                if (deg > 2) {
+                    dRdx += LG_SH_C3_0 * sh[9 * 3 + c] * 3.0f * 2.0f * xy + LG_SH_C3_1 * sh[10 * 3 + c] * yz +
+                            LG_SH_C3_2 * sh[11 * 3 + c] * -2.0f * xy + LG_SH_C3_3 * sh[12 * 3 + c] * -3.0f * 2.0f * xz +
+                            LG_SH_C3_4 * sh[13 * 3 + c] * (-3.0f * xx + 4.0f * zz - yy) + LG_SH_C3_5 * sh[14 * 3 + c] * 2.0f * xz +
+                            LG_SH_C3_6 * sh[15 * 3 + c] * 3.0f * (xx - yy);
+                    dRdy += LG_SH_C3_0 * sh[9 * 3 + c] * 3.0f * (xx - yy) + LG_SH_C3_1 * sh[10 * 3 + c] * xz +
+                            LG_SH_C3_2 * sh[11 * 3 + c] * (-3.0f * yy + 4.0f * zz - xx) +
+                            LG_SH_C3_3 * sh[12 * 3 + c] * -3.0f * 2.0f * yz + LG_SH_C3_4 * sh[13 * 3 + c] * -2.0f * xy +
+                            LG_SH_C3_5 * sh[14 * 3 + c] * -2.0f * yz + LG_SH_C3_6 * sh[15 * 3 + c] * -3.0f * 2.0f * xy;
+                    dRdz += LG_SH_C3_1 * sh[10 * 3 + c] * xy + LG_SH_C3_2 * sh[11 * 3 + c] * 4.0f * 2.0f * yz +
+                            LG_SH_C3_3 * sh[12 * 3 + c] * 3.0f * (2.0f * zz - xx - yy) +
+                            LG_SH_C3_4 * sh[13 * 3 + c] * 4.0f * 2.0f * xz + LG_SH_C3_5 * sh[14 * 3 + c] * (xx - yy);
+                }
+            }
+        }
+        J[3 * c] = dRdx; J[3 * c + 1] = dRdy; J[3 * c + 2] = dRdz;
+    }
+}
+
+// lg_backward_sh with the direction Jacobian handed in (lg_sh_dir_jacobian) instead of the coefficients: dL/dSH through store(k, c, value),
+// the view-direction term into dmean[3].  Same operations in the same order as lg_backward_sh.
+template <typename StoreFn>
+LG_HD void lg_backward_sh_jac(int deg, const float J[9], float px, float py, float pz, const float* campos, const float dRGB[3],
+                              float dmean[3], StoreFn store)
+{
+    float ox = px - campos[0], oy = py - campos[1], oz = pz - campos[2];
+    float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    float x = ox / len, y = oy / len, z = oz / len;
+    float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+    for (int c = 0; c < 3; c++) {
+        const float d = dRGB[c];
+        store(0, c, LG_SH_C0 * d);
+        if (deg > 0) {
+            store(1, c, -LG_SH_C1 * y * d);
+            store(2, c, LG_SH_C1 * z * d);
+            store(3, c, -LG_SH_C1 * x * d);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                store(4, c, LG_SH_C2_0 * xy * d);
+                store(5, c, LG_SH_C2_1 * yz * d);
+                store(6, c, LG_SH_C2_2 * (2.0f * zz - xx - yy) * d);
+                store(7, c, LG_SH_C2_3 * xz * d);
+                store(8, c, LG_SH_C2_4 * (xx - yy) * d);
+                if (deg > 2) {
+                    store(9, c, LG_SH_C3_0 * y * (3.0f * xx - yy) * d);
+                    store(10, c, LG_SH_C3_1 * xy * z * d);
+                    store(11, c, LG_SH_C3_2 * y * (4.0f * zz - xx - yy) * d);
+                    store(12, c, LG_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * d);
+                    store(13, c, LG_SH_C3_4 * x * (4.0f * zz - xx - yy) * d);
+                    store(14, c, LG_SH_C3_5 * z * (xx - yy) * d);
+                    store(15, c, LG_SH_C3_6 * x * (xx - 3.0f * yy) * d);
+                }
+            }
+        }
+        ddx += J[3 * c] * d; ddy += J[3 * c + 1] * d; ddz += J[3 * c + 2] * d;
+    }
+    float sum2 = ox * ox + oy * oy + oz * oz;
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+    dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+    dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+}

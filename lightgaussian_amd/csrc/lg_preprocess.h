@@ -77,13 +77,14 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
               const float* __restrict__ colors_precomp,
               const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
               const float* __restrict__ cov3D_precomp, GeomView g, int32_t* __restrict__ radii, int32_t* __restrict__ zero_count,
-              float* __restrict__ zero_score, uint32_t* __restrict__ clear_words, uint32_t n_clear)
+              float* __restrict__ zero_score, uint32_t* __restrict__ clear_words, uint32_t n_clear, int save_jac)
 {
     // DIRECT (default): every visible lane reads its own SH row with dwordx4 loads (read_row_direct) and no LDS is
     // allocated for SH (occupancy is then register-limited, 5 waves/SIMD, instead of LDS-limited, 3).  The LDS-staged
     // variant is kept behind the LG_K1_LDS environment switch as the cross-check of the direct reads.
     __shared__ __attribute__((aligned(16))) float sh_rows[DIRECT ? 4 : LG_PP * LG_SH_MAXF];
     __shared__ float4 st_rec[LG_PP * 3]; // records leave through LDS as coalesced 16-byte stores
+    __shared__ __attribute__((aligned(16))) float st_jac[LG_PP * 9];   // ... and so do the SH direction Jacobians (save_jac)
     static_assert(LG_REC_F4 == 3, "coalesced record store assumes packed 48-byte records");
     const uint32_t lane = threadIdx.x;
     const int i0 = blockIdx.x * LG_PP;
@@ -179,6 +180,12 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
                     for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
                 }
                 lg_sh_to_rgb(D, sh, px, py, pz, cp, rgb, cb);
+                if (save_jac) {
+                    float J[9];
+                    lg_sh_dir_jacobian(D, sh, px, py, pz, cp, J);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) st_jac[9 * lane + k] = J[k];
+                }
             }
             st_rec[3 * lane + 0] = make_float4(sp.x, sp.y, sp.ha, sp.nb);
             st_rec[3 * lane + 1] = make_float4(sp.hc, op, rgb[0], rgb[1]);
@@ -203,6 +210,14 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 #pragma unroll
         for (int k = 0; k < 3; k++)
             if ((int)(k * LG_PP + lane) < 3 * nrec) g.rec[3 * (size_t)i0 + k * LG_PP + lane] = st_rec[k * LG_PP + lane];
+        if (save_jac && shs && !skip_color) {
+            // 36 bytes per Gaussian, contiguous for the workgroup (i0 is a multiple of 64: 16-byte aligned); rows of culled Gaussians
+            // carry stale LDS contents, nothing reads them
+            float* dstj = g.shjac + 9 * (size_t)i0;
+            const int nfl = 9 * nrec, nvec = nfl >> 2;
+            for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dstj)[q] = reinterpret_cast<const float4*>(st_jac)[q];
+            for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dstj[f] = st_jac[f];
+        }
     }
     // (no global visible-counter: 47k same-address atomics serialise at ~11 ns each -- more than the whole kernel)
     // largest depth of the workgroup (bit pattern; positive floats order like integers), for the packed sort key.
@@ -219,7 +234,10 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     if (lane == 0) {
         g.blk_dmax[blockIdx.x] = dmax | (any_violation ? 0x80000000u : 0u);
         g.blk_sum[blockIdx.x] = tsum;
-        if (blockIdx.x == 0) g.counters[8] = 0u;   // arrival counter of lg_scan_blocks (the scratch buffer arrives uninitialised)
+        if (blockIdx.x == 0) {
+            g.counters[8] = 0u;   // arrival counter of lg_scan_blocks (the scratch buffer arrives uninitialised)
+            g.counters[9] = (save_jac && shs && !skip_color) ? LG_SHJAC_MAGIC : 0u;   // K9: the Jacobian rows of this view exist
+        }
     }
 }
 
@@ -229,7 +247,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 // through LDS so that global traffic is coalesced 16-byte accesses.
 // 151 VGPRs -> 3 waves/SIMD.  Forcing 4 (amdgpu_waves_per_eu, 12 spilled registers) was measured: 0.37 -> 0.50 ms.
 // Reading the SH rows directly per lane as K1 does (only the visible rows, no input staging) was measured: 0.380 vs 0.380 ms.
-template <bool RAW>
+template <bool RAW, bool JAC>
 // 155 VGPRs -> 3 waves/SIMD.  Forcing 4 (-DLG_K9_WAVES=4: 128 VGPRs, 76 B/lane of scratch) was measured in round 3:
 // 0.384 -> 0.594 ms -- the spills cost more than the fourth wave hides; 5 is not reachable (the compiler gives up at 157).
 #ifdef LG_K9_WAVES
@@ -244,7 +262,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
                   const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                   const int32_t* __restrict__ radii, const float4* __restrict__ rec,
                   const uint32_t* __restrict__ counters, const uint32_t* __restrict__ meta, uint32_t S, const uint32_t* __restrict__ touched,
-                  const uint32_t* __restrict__ offsets, const float4* __restrict__ part,
+                  const uint32_t* __restrict__ offsets, const float4* __restrict__ part, const float* __restrict__ shjac,
                   float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                   float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                   float* __restrict__ dL_dscales, float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
@@ -260,13 +278,17 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
     // counters[0] != 0: the forward aborted this view on the device (lg_forward_bounded overflow); there are no rows.
     // meta[2] != S: this backward was given another segment length than the forward that filled the buffers (lg_view.segment_length
     // must match): lg_blend_bwd refused to run, there are no rows either -- zero gradients, and LG_FLAG_DEBUG reports it
-    const bool vis = (i < N) && radii[i] > 0 && counters[0] == 0u && meta[2] == S;
+    const bool vis = (i < N) && radii[i] > 0 && counters[0] == 0u && meta[2] == S && (!JAC || counters[9] == LG_SHJAC_MAGIC);
     const uint64_t vmask = __ballot(vis);
     const bool split = RAW && shs_rest != nullptr;
     const int rowf = split ? 3 * (M - 1) : 3 * M;
     const int rows = min(LG_PP, N - i0);
     const bool use_sh = (shs != nullptr) && (dL_dshs != nullptr);
-    if (use_sh && vmask && rowf > 0) {
+    // JAC: the forward left d rgb / d direction of every visible Gaussian (LG_FLAG_SAVE_SH_JACOBIAN; the host instantiates this variant
+    // when the view carries the flag): the coefficients are not read at all.  The marker word says the rows of THIS view are there; a
+    // backward handed the flag after a forward without it finds no marker and writes zero gradients (LG_FLAG_DEBUG reports it), like
+    // a backward with another segment length.
+    if (use_sh && !JAC && vmask && rowf > 0) {
         stage_sh_rows(split ? shs_rest : shs, i0, rows, rowf, vmask, sh_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -348,6 +370,12 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
         } else if (use_sh) {
             const uint32_t cb = __float_as_uint(q2.w) >> LG_ID_BITS;
             float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
+            if (JAC) {
+                const float* jr = shjac + 9 * (size_t)i;          // 36-byte rows: dword-aligned 16-byte loads
+                const lg_f4u j0 = reinterpret_cast<const lg_f4u*>(jr)[0], j1 = reinterpret_cast<const lg_f4u*>(jr)[1];
+                const float J[9] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, jr[8] };
+                lg_backward_sh_jac(D, J, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh[k * 3 + c] = v; });
+            } else {
             float sh[LG_SH_MAXF];
             const float* row = sh_rows + lane * rowf;
             const int nact = (D + 1) * (D + 1) * 3;
@@ -367,6 +395,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
                 for (int k = 0; k < LG_SH_MAXF; k++) sh[k] = (k < nact) ? row[k] : 0.0f;
             }
             lg_backward_sh(D, sh, px, py, pz, cp, dRGB, m3, [&](int k, int c, float v) { dsh[k * 3 + c] = v; });
+            }
         }
         if (cov3D_precomp) {
 #pragma unroll
@@ -388,40 +417,54 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
         }
     }
     if (use_sh) {
-        // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced
+        // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced.  (HALVES = 2 sends the
+        // 64 rows out in two halves through half the LDS -- 6 KB per wave, four waves per SIMD with the 107 VGPRs of the JAC variant
+        // instead of three: measured in round 4, 0.2481 / 0.2451 vs 0.2476 / 0.2481 ms, nothing -- the kernel moves 1.25 GB at 5.1 TB/s)
+        constexpr int HALVES = 1, HROWS = LG_PP / HALVES;
         __builtin_amdgcn_wave_barrier();
-        float* row = sh_rows + lane * rowf;
-        if (split) {
-            if (i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
+        if (split && i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
 #pragma unroll
-            for (int k = 3; k < LG_SH_MAXF; k++)
-                if (k - 3 < rowf) row[k - 3] = dsh[k];
-        } else if ((rowf & 3) == 0) {
+        for (int hf = 0; hf < HALVES; hf++) {
+            if ((int)(lane / HROWS) == hf) {
+                float* row = sh_rows + (lane % HROWS) * rowf;
+                if (split) {
 #pragma unroll
-            for (int q = 0; q < LG_SH_MAXF / 4; q++)
-                if (q * 4 < rowf) reinterpret_cast<float4*>(row)[q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
-        } else {
+                    for (int k = 3; k < LG_SH_MAXF; k++)
+                        if (k - 3 < rowf) row[k - 3] = dsh[k];
+                } else if ((rowf & 3) == 0) {
 #pragma unroll
-            for (int k = 0; k < LG_SH_MAXF; k++)
-                if (k < rowf) row[k] = dsh[k];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float* dst = (split ? dL_dshs_rest : dL_dshs) + (size_t)i0 * rowf;
-        const int nfl = rows * rowf;
-        if (nfl > 0) {
-            if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-                const int nvec = nfl >> 2;
-                // gradient rows are written once and read next by the optimizer, long after this view: non-temporal stores (round 4).
-                // This kernel itself does not get faster (0.386 vs 0.388 ms) -- the NEXT view's K1 does, 0.204 -> 0.195 ms: 576 MB of
-                // gradients no longer push its inputs out of the cache
-                typedef float lg_f4v __attribute__((ext_vector_type(4)));
-                for (int q = (int)lane; q < nvec; q += LG_PP)
-                    __builtin_nontemporal_store(reinterpret_cast<const lg_f4v*>(sh_rows)[q], reinterpret_cast<lg_f4v*>(dst) + q);
-                for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
-            } else {
-                for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+                    for (int q = 0; q < LG_SH_MAXF / 4; q++)
+                        if (q * 4 < rowf) reinterpret_cast<float4*>(row)[q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LG_SH_MAXF; k++)
+                        if (k < rowf) row[k] = dsh[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int r0 = hf * HROWS;                                       // first row of this half inside the workgroup
+            float* dst = (split ? dL_dshs_rest : dL_dshs) + ((size_t)i0 + r0) * rowf;
+            const int nfl = max(0, min(HROWS, rows - r0)) * rowf;
+            if (nfl > 0) {
+                if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+                    const int nvec = nfl >> 2;
+                    // gradient rows are written once and read next by the optimizer, long after this view: non-temporal stores (round 4).
+                    // This kernel itself does not get faster (0.386 vs 0.388 ms) -- the NEXT view's K1 does, 0.204 -> 0.195 ms: 576 MB of
+                    // gradients no longer push its inputs out of the cache
+                    typedef float lg_f4v __attribute__((ext_vector_type(4)));
+                    for (int q = (int)lane; q < nvec; q += LG_PP)
+                        __builtin_nontemporal_store(reinterpret_cast<const lg_f4v*>(sh_rows)[q], reinterpret_cast<lg_f4v*>(dst) + q);
+                    for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+                } else {
+                    for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+                }
+            }
+            if (hf + 1 < HALVES) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();             // the copy has read the rows before the next half overwrites them
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }

@@ -184,7 +184,8 @@ def _prep(t, dev):
 class _Call:
     """Holds the tensors referenced by the C structs alive for the duration of a call."""
 
-    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact, sh_rest=None, raw=False, opts=None):
+    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, exact, sh_rest=None, raw=False, opts=None,
+                 differentiated=False):
         opts = opts if opts is not None else resolve_options()
         self.opts = opts
         dev = means3D.device
@@ -206,6 +207,10 @@ class _Call:
         N = self.means3D.shape[0] if self.means3D is not None else 0
         M = 0 if self.sh is None else int(self.sh.shape[1]) + (0 if sh_rest is None else int(sh_rest.shape[1]))
         flags = _lib.FLAG_RAW_PARAMS if raw else 0
+        if differentiated and "LG_NO_SH_JACOBIAN" not in os.environ:     # (cross-check switch: K9 reads the SH coefficients as in rounds 1-3)
+            # a backward will follow: K1 leaves the SH direction Jacobian (36 B per visible Gaussian) so that K9 need not read the
+            # coefficients again (LG_FLAG_SAVE_SH_JACOBIAN; no-grad forwards do not pay the extra write)
+            flags |= _lib.FLAG_SAVE_SH_JACOBIAN
         if rs.debug:
             flags |= _lib.FLAG_DEBUG
         if opts["fast_exp"] and not exact:
@@ -413,7 +418,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         count = bool(rs.f_count)
         opts = resolve_options(options)
-        call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count, opts=opts)
+        call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count, opts=opts,
+                     differentiated=any(ctx.needs_input_grad))
         with torch.cuda.device(call.dev):
             color, radii, gcount, score, geom, binning, img, num_rendered = _native_forward(lib, call, rs, count)
         ctx.raster_settings = rs
@@ -438,7 +444,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         grad_color = grads[2] if rs.f_count else grads[0]
         means3D, sh, colors, opac, scales, rots, cov, radii, geom, binning, img = ctx.saved_tensors
-        call = _Call(rs, means3D, sh, colors, opac, scales, rots, cov, exact=bool(rs.f_count), opts=ctx.opts)
+        call = _Call(rs, means3D, sh, colors, opac, scales, rots, cov, exact=bool(rs.f_count), opts=ctx.opts, differentiated=True)
         dev, N, M = call.dev, call.N, call.M
         H, W = int(rs.image_height), int(rs.image_width)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -481,7 +487,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if rs.f_count:
             raise Exception("raw-parameter rasterisation is a training path; use count_render for significance")
         rest = features_rest if (features_rest is not None and features_rest.shape[1] > 0) else None
-        call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True, opts=opts)
+        call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True, opts=opts,
+                     differentiated=any(ctx.needs_input_grad))
         with torch.cuda.device(call.dev):
             color, radii, _gc, _sc, geom, binning, img, num_rendered = _native_forward(lib, call, rs, False)
         ctx.raster_settings = rs
@@ -506,7 +513,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         lib = _lib.load()
         rs = ctx.raster_settings
         xyz, dc, rest, opac, scales, rots, radii, geom, binning, img = ctx.saved_tensors
-        call = _Call(rs, xyz, dc, None, opac, scales, rots, None, exact=False, sh_rest=rest, raw=True, opts=ctx.opts)
+        call = _Call(rs, xyz, dc, None, opac, scales, rots, None, exact=False, sh_rest=rest, raw=True, opts=ctx.opts, differentiated=True)
         dev, N = call.dev, call.N
         H, W = int(rs.image_height), int(rs.image_width)
         f32 = dict(dtype=torch.float32, device=dev)

@@ -235,3 +235,31 @@ def test_render_scaling_modifier_with_python_covariance(mod):
     kw["scale_modifier"] = mod
     ref = oracle.forward(**kw)
     assert np.array_equal(img.cpu().numpy().view(np.uint32), ref.color.view(np.uint32))
+
+
+# ---- round 4: the SH direction Jacobian saved by K1 (LG_FLAG_SAVE_SH_JACOBIAN) ---------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True], ids=["literal", "fused"])
+@pytest.mark.parametrize("D", [0, 1, 2, 3])
+def test_backward_with_the_saved_sh_jacobian_is_bit_identical_to_the_backward_that_reads_the_coefficients(D, fused, monkeypatch):
+    """A differentiated forward makes K1 leave d rgb / d (view direction) per visible Gaussian (36 B) and K9 skip the SH coefficients
+    (388 MB per view at C3).  Same operations in the same order: every gradient bit-identical to the path that re-reads the coefficients
+    (LG_NO_SH_JACOBIAN=1, rounds 1-3), for every active degree, stored degree 3."""
+    from lightgaussian_amd.gaussian_renderer import render
+    g, cam = _scene(active=D, stored=3, seed=41)
+    W, H = 144, 96
+    dev = torch.device(DEV)
+    bg = torch.tensor([0.1, 0.3, 0.2], device=dev)
+    gimg = torch.from_numpy(np.random.RandomState(23).randn(3, H, W).astype(np.float32)).to(dev)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("LG_NO_SH_JACOBIAN", "1")
+        else:
+            monkeypatch.delenv("LG_NO_SH_JACOBIAN", raising=False)
+        pc = g.to(dev).requires_grad_(True)
+        pkg = render(cam.to(dev), pc, syn.PipelineParams(), bg, options={"fuse_getters": fused})
+        (pkg["render"] * gimg).sum().backward()
+        res.append([pkg["render"].detach().clone()] + [getattr(pc, n).grad.clone() for n in RAW])
+    for n, a, b in zip(("image",) + RAW, *res):
+        assert torch.equal(a, b), n
+    assert float(res[0][1].abs().sum()) > 0 and (D == 0 or float(res[0][3].abs().sum()) > 0)
