@@ -419,7 +419,9 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
     if (use_sh) {
         // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced.  (HALVES = 2 sends the
         // 64 rows out in two halves through half the LDS -- 6 KB per wave, four waves per SIMD with the 107 VGPRs of the JAC variant
-        // instead of three: measured in round 4, 0.2481 / 0.2451 vs 0.2476 / 0.2481 ms, nothing -- the kernel moves 1.25 GB at 5.1 TB/s)
+        // instead of three: measured in round 4, 0.2481 / 0.2451 vs 0.2476 / 0.2481 ms, nothing -- the kernel moves 1.25 GB at 5.1 TB/s.
+        // Every lane storing its own row with 16-byte stores at the row stride, no LDS at all: 0.26 -> 0.79 ms -- partial-line WRITES are
+        // what the staging is for; strided 16-byte READS, K1's way, are fine.)
         constexpr int HALVES = 1, HROWS = LG_PP / HALVES;
         __builtin_amdgcn_wave_barrier();
         if (split && i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
