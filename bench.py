@@ -199,7 +199,7 @@ def dry_run(args, rank, world):
 def algorithmic_bytes(N, V, R, P, M):
     """SURVEY.md section 8d per-view algorithmic HBM bytes, split per kernel."""
     return {
-        "preprocess": 16 * N + (76 + 12 * M + 28) * V,
+        "preprocess": 16 * N + (76 + 12 * M + 28) * V + 36 * V,   # + the SH direction Jacobian a differentiated forward leaves for K9 (r4)
         "scan": 8 * N,
         "duplicate": 8 * R,
         "sort": 16 * R,
@@ -208,7 +208,7 @@ def algorithmic_bytes(N, V, R, P, M):
         "blend_fwd_count": 44 * R + 20 * P + 8 * N,
         "score": 12 * N,
         "blend_bwd": 104 * R + 20 * P,                # entry 8 + rect 16 + record 36 + gradient row 44
-        "preprocess_bwd": (108 + 12 * M) * V + (56 + 12 * M) * N + 52 * R,
+        "preprocess_bwd": (108 + 36) * V + (56 + 12 * M) * N + 52 * R,   # r4: 36 B of Jacobian per visible Gaussian instead of its 12 M bytes of SH coefficients
         "loss_fwd": 3 * P * (8 + 12),   # read image + gt, write the three partial-derivative maps (per channel-pixel)
         "loss_bwd": 3 * P * (12 + 8 + 4),
     }
@@ -614,7 +614,7 @@ def main():
         # above rocprof on the VALU-bound blend kernels).  Both are always printed.
         sym = {"blend_bwd": "lg_blend_bwd<false>" if not args.exact_exp else "lg_blend_bwd<true>",
                "blend_fwd": "lg_blend_fwd<false, false, false, true>", "blend_fwd_count": "lg_blend_fwd<true, false, true, false>",
-               "preprocess": "lg_preprocess<true, true>", "preprocess_bwd": "lg_preprocess_bwd<true>"}.get(dom)
+               "preprocess": "lg_preprocess<true, true>", "preprocess_bwd": "lg_preprocess_bwd<true, true>"}.get(dom)
         prof_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_profile_{args.mode}.json")
         stats_file = f"profiles/{PROFILE_ROUND}_{args.mode}_kernel_stats.csv"
         c3 = args.n_gaussians == 3_000_000 and (W, H) == (1920, 1080) and abs(args.scale - 0.004) < 1e-12 and args.scene == "uniform"
