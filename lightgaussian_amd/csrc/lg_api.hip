@@ -6,7 +6,7 @@
 //   lg_preprocess.h  K1 lg_preprocess<RAW>, K8+K9 lg_preprocess_bwd<RAW>            (per Gaussian, HBM-bound)
 //   lg_binning.h     K2 lg_scan_blocks, K3 lg_duplicate, lg_tile_sort / _long (second sort stage), lg_tile_ranges (one-stage cross-check only),
 //                    lg_work_order (K2-K5 all hand-written; lg_sort.h = K4)
-//   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (per 32x32 tile, LDS-tiled)
+//   lg_loss.h        lg_loss_fwd / lg_loss_bwd: fused L1 + SSIM of the training step             (a wave per 64-column strip, register ring)
 //   lg_prune.h       lg_select_pass, lg_v_imp_score_kernel, lg_prune_mask_kernel: device-resident prune epilogue (radix selects)
 //   lg_knn.h         distCUDA2 (simple-knn): exact 3-nearest-neighbour mean squared distance on a multi-level uniform grid
 //   lg_compact.h     lg_compact_plan / lg_compact_rows: one scan + one launch compacting all Gaussian tensors after a prune
@@ -729,7 +729,7 @@ extern "C" int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img
     hipStream_t stream = (hipStream_t)stream_p;
     const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
     LossView lv = carve_loss(state, C, H, W);
-    dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
+    dim3 grid(lg_loss_strips(W), lg_loss_segs(H), C);      // one wave per (strip of 64 columns, LG_LOSS_TH rows, plane)
     if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
     if (flags & LG_FLAG_L1_ONLY) {
         ProfScope ps(prof, "l1_fwd", stream);
@@ -743,7 +743,7 @@ extern "C" int lg_loss_forward(int32_t C, int32_t H, int32_t W, const float* img
     }
     {
         ProfScope ps(prof, "loss_fwd", stream);
-        lg_loss_fwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, lv.partials);
+        lg_loss_fwd<<<grid, LG_LOSS_STRIP, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, lv.partials);
         KCHECK("lg_loss_fwd");
         lg_loss_finalize<<<1, 256, 0, stream>>>((int)(grid.x * grid.y * grid.z), 1.0 / ((double)C * H * W), lv.partials, out_l1_ssim);
         KCHECK("lg_loss_finalize");
@@ -760,7 +760,7 @@ extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* im
     hipStream_t stream = (hipStream_t)stream_p;
     const bool debug = flags & LG_FLAG_DEBUG, prof = flags & LG_FLAG_PROFILE;
     LossView lv = carve_loss(const_cast<void*>(state), C, H, W);
-    dim3 grid((W + LG_LOSS_TILE - 1) / LG_LOSS_TILE, (H + LG_LOSS_TILE - 1) / LG_LOSS_TILE, C);
+    dim3 grid(lg_loss_strips(W), lg_loss_segs(H), C);
     if (grid.y > 65535) return fail(LG_ERR_INVALID_ARGUMENT, "image too large");
     if (flags & LG_FLAG_L1_ONLY) {
         ProfScope ps(prof, "l1_bwd", stream);
@@ -771,7 +771,7 @@ extern "C" int lg_loss_backward(int32_t C, int32_t H, int32_t W, const float* im
     }
     {
         ProfScope ps(prof, "loss_bwd", stream);
-        lg_loss_bwd<<<grid, 256, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, dL_dl1, scale_l1, dL_dssim, scale_ssim,
+        lg_loss_bwd<<<grid, LG_LOSS_STRIP, 0, stream>>>(H, W, img, gt, lv.dmu1, lv.dsig1, lv.dsig12, dL_dl1, scale_l1, dL_dssim, scale_ssim,
                                               (float)(1.0 / ((double)C * H * W)), dL_dimg);
         KCHECK("lg_loss_bwd");
     }
