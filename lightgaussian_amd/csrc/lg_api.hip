@@ -205,8 +205,15 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (N > 0) {
         {
             ProfScope ps(prof, "preprocess", stream);
+            // K1 runs FASTER with fewer waves in flight (round 4, measured on one box by padding its LDS: 20 waves per CU -- what its
+            // 92 VGPRs allow -- 0.233 ms, 15: 0.217, 13: 0.201, 12: 0.1995, 11: 0.203, 7: 0.220, 3: 0.34; C2 0.082 -> 0.074, 6 M at 1600x1060 0.444 ->
+            // 0.394, heavy-tailed scene 0.230 -> 0.195): every visible lane reads
+            // its 180-byte SH row as twelve 16-byte pieces, and with all twenty waves' rows in flight the pieces of one cache line
+            // are served by several fetches of that line.  Unused dynamic LDS caps the kernel at 12 waves per CU.
+            // (K9 is the opposite: capped below its 13 waves per CU it slows down at once, 0.262 -> 0.283 ms at 11.)
+            const size_t k1_dyn = LG_K1_PAD_LDS;
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
-    lg_preprocess<RAWP, DIR><<<nblk, LG_PP, 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
+    lg_preprocess<RAWP, DIR><<<nblk, LG_PP, (DIR) ? k1_dyn : 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
                                                                       g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score, \

@@ -13,6 +13,9 @@
 #define LG_ID_BITS 29            // blend record, last word: Gaussian id | SH clamp flags << 29
 #define LG_ID_MASK ((1u << LG_ID_BITS) - 1u)
 #define LG_SH_MAXF 48 // floats per SH row at M = 16
+#ifndef LG_K1_PAD_LDS
+#define LG_K1_PAD_LDS 7900 // dynamic LDS the host adds to K1's 5.4 KB per wave: 12 waves per CU (lg_api.hip, at the launch)
+#endif
 #define LG_COOP_ROWS 48u // K9: splats with more tile instances than this are gathered by the whole wave
 
 // cooperative copy of the wave's SH rows into LDS (flat layout, row stride = rowf floats)
@@ -104,7 +107,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     if (i < N) {
         px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2];
         // near-plane test first so culled Gaussians cost 12 bytes of reads (hoisting the scale / rotation / opacity loads
-        // above this branch was measured: no change)
+        // above this branch was measured twice -- round 2 at 20 waves per CU, round 4 at 12: no change)
         const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
         if (vz > 0.2f) {
             if (cov3D_precomp) {
