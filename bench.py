@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--segment-length", type=int, default=0, help="rasterizer option segment_length (0 = library default 512): per-tile lists longer than this "
                     "are cut into independent (tile, segment) work items of the backward")
     ap.add_argument("--long-tiles", choices=["serial", "auto", "parallel"], default="auto", help="rasterizer option long_tiles (walk of outlier tile lists in the forward)")
+    ap.add_argument("--spatial-order", action="store_true", help="NOT the frozen workload: the same Gaussians permuted into Morton order of their "
+                    "centres (lightgaussian_amd.synthetic.morton_permutation) -- what ordering a model spatially is worth; reported as a separate measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the untimed literal-getter-pattern leg (profiling runs)")
@@ -260,6 +262,8 @@ def main():
     g_cpu = syn.make_gaussians(N, sh_degree=args.sh_degree, log_scale_mean=math.log(args.scale))
     if args.scene == "heavy":
         syn.make_heavy_tailed(g_cpu)
+    if args.spatial_order:
+        syn.permute_(g_cpu, syn.morton_permutation(g_cpu._xyz))
     pc = g_cpu.to(dev)
     pipe = syn.PipelineParams()
     bg = torch.zeros(3, device=dev)  # black, prune_finetune.py:87-88

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--lambda-dssim", type=float, default=0.2)     # arguments/__init__.py
+    ap.add_argument("--fused-adam", action="store_true", help="what `python -m lightgaussian_amd.run --fused-adam` switches on")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     truth = syn.make_gaussians(args.n_gaussians).to(dev)
@@ -46,6 +47,9 @@ def main():
     g._features_dc += 0.1 * torch.randn(g._features_dc.shape, generator=gen)
     g._opacity += 0.3 * torch.randn(g._opacity.shape, generator=gen)
     g = g.to(dev).requires_grad_(True)
+    if args.fused_adam:
+        from lightgaussian_amd import run as lg_run
+        lg_run.fused_adam(True)
     opt = torch.optim.Adam([{"params": [g._xyz], "lr": 1.6e-6}, {"params": [g._features_dc], "lr": 2.5e-3},
                             {"params": [g._features_rest], "lr": 2.5e-3 / 20.0}, {"params": [g._opacity], "lr": 0.05},
                             {"params": [g._scaling], "lr": 0.005}, {"params": [g._rotation], "lr": 0.001}], lr=0.0, eps=1e-15)
@@ -69,7 +73,7 @@ def main():
     dt = time.perf_counter() - t0
     n = min(args.views, args.iters)
     print(f"{args.iters} iterations, {args.n_gaussians} Gaussians, {args.width}x{args.height}: {dt / args.iters * 1e3:.2f} ms/iteration "
-          f"(render fwd+bwd + L1/SSIM + Adam); mean loss first {n} iterations {first / n:.5f} -> last {n} {last / n:.5f}")
+          f"(render fwd+bwd + L1/SSIM + Adam{' fused' if args.fused_adam else ''}); mean loss first {n} iterations {first / n:.5f} -> last {n} {last / n:.5f}")
     assert last < first, "the loss did not go down"
 
 

@@ -8,6 +8,8 @@
          from its own shard of the train list, gradients are averaged over the ranks in front of every optimizer.step() (rows no
          rank saw are not exchanged), add_densification_stats / max_radii2D are reduced, prune_list is sharded by camera, ranks
          other than 0 write under <model_path>/.rank<r>)
+    python -m lightgaussian_amd.run --fused-adam /path/to/prune_finetune.py ...
+        (opt-in, outside the replaced path: torch.optim.Adam as the trainers construct it, but with fused=True -- fused_adam() below)
 
 Why a runner.  The trainers import their collaborators by name from their own directory, which Python puts first on sys.path:
     from utils.loss_utils import l1_loss, ssim                 prune_finetune.py:15, distill_train.py:15, train_densify_prune.py
@@ -249,6 +251,35 @@ def unpatch_reference():
     _REPORT.clear()
 
 
+_ADAM_INIT = {}
+
+
+def fused_adam(enable=True):
+    """run.py --fused-adam (opt-in; the optimizer is NOT part of the path this package replaces -- SURVEY 2, row 6 -- but it is what an
+    iteration of the unmodified trainers spends most of its time in once the render is fast): the reference builds
+    torch.optim.Adam(l, lr=0.0, eps=1e-15) (scene/gaussian_model.py:training_setup), which runs as ~8 multi-tensor kernels over the
+    six parameter tensors and their moments; the same constructor with fused=True is ONE kernel per step.  Same update rule, float
+    rounding aside; the optimizer-state surgery of prune / densify (exp_avg, exp_avg_sq by key) works on it unchanged.  Only Adam
+    instances created while this is active, over CUDA parameters, and without an explicit fused / foreach argument are affected."""
+    import torch
+    if enable and "orig" not in _ADAM_INIT:
+        orig = torch.optim.Adam.__init__
+        _ADAM_INIT["orig"] = orig
+
+        def __init__(self, params, *args, **kw):
+            params = list(params)
+            if "fused" not in kw and "foreach" not in kw:
+                flat = [p for g in params for p in (g["params"] if isinstance(g, dict) else [g])]
+                flat = [p for g in flat for p in (g if isinstance(g, (list, tuple)) else [g])]
+                if flat and all(torch.is_tensor(p) and p.is_cuda and p.is_floating_point() for p in flat):
+                    kw["fused"] = True
+            orig(self, params, *args, **kw)
+
+        torch.optim.Adam.__init__ = __init__
+    elif not enable and "orig" in _ADAM_INIT:
+        torch.optim.Adam.__init__ = _ADAM_INIT.pop("orig")
+
+
 def _redirect_model_path(argv, rank):
     """Ranks other than 0 of a data-parallel run write their outputs (cfg_args, point clouds, checkpoints, imp_score.npz: the
     trainers write them unconditionally) under <model_path>/.rank<r> instead of on top of rank 0's files.  -m / --model_path is
@@ -267,7 +298,7 @@ def _redirect_model_path(argv, rank):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    distributed = no_patch = verbose = False
+    distributed = no_patch = verbose = adam = False
     backend = "nccl"
     while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
         flag = argv.pop(0)
@@ -277,10 +308,12 @@ def main(argv=None):
             no_patch = True
         elif flag == "--verbose":
             verbose = True
+        elif flag == "--fused-adam":
+            adam = True
         elif flag.startswith("--backend="):       # gloo: CPU tests of the launcher with a stand-in trainer (the rasterizer has no CPU path)
             backend = flag.split("=", 1)[1]
         else:
-            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose, then the script and ITS arguments)")
+            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose --fused-adam, then the script and ITS arguments)")
     if not argv:
         raise SystemExit(__doc__)
     script = os.path.abspath(argv[0])
@@ -315,6 +348,8 @@ def main(argv=None):
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             else:
                 dist.init_process_group(backend)
+    if adam:
+        fused_adam(True)
     if not no_patch:
         # --distributed is DATA-PARALLEL training (lightgaussian_amd.dp): a camera shard per rank, the gradients averaged over the
         # ranks in front of every optimizer.step(), prune_list sharded by camera; the ranks stay bit-identical replicas of one model
@@ -325,6 +360,8 @@ def main(argv=None):
     try:
         runpy.run_path(script, run_name="__main__")
     finally:
+        if adam:
+            fused_adam(False)
         if distributed:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():

@@ -150,3 +150,23 @@ def test_runner_rebinds_what_the_trainer_script_then_imports_by_name(tmp_path):
     literal = run("--no-patch")
     assert literal == {"render": "gaussian_renderer", "count_render": "gaussian_renderer", "l1_loss": "utils.loss_utils", "ssim": "utils.loss_utils",
                        "prune_list": "prune", "calculate_v_imp_score": "prune"}
+
+
+def test_fused_adam_switch_only_touches_cuda_parameter_lists_and_restores():
+    """run.py --fused-adam: torch.optim.Adam as the trainers construct it (scene/gaussian_model.py:training_setup), fused=True added
+    for CUDA parameters only; explicit fused / foreach arguments and CPU parameters are left alone; switching off restores torch's
+    own constructor."""
+    orig = torch.optim.Adam.__init__
+    lg_run.fused_adam(True)
+    try:
+        assert torch.optim.Adam.__init__ is not orig
+        p = [torch.nn.Parameter(torch.randn(4, 3))]
+        opt = torch.optim.Adam([{"params": p, "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)      # the reference's call shape
+        assert not opt.defaults.get("fused")                                                       # CPU parameters: untouched
+        p[0].grad = torch.ones_like(p[0])
+        opt.step()
+        assert torch.optim.Adam([torch.nn.Parameter(torch.randn(2))], foreach=False).defaults["foreach"] is False
+        lg_run.fused_adam(True)                                                                    # idempotent
+    finally:
+        lg_run.fused_adam(False)
+    assert torch.optim.Adam.__init__ is orig

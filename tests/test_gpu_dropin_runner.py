@@ -264,3 +264,37 @@ def test_vectree_search_sites_through_the_patched_module(standins):
                 assert abs(da - db) <= 1e-5 * max(da, 1e-6)
         same = (i0 == i1)[0]
         assert torch.equal(q0[0][same], q1[0][same])
+
+
+def test_fused_adam_switch_gives_the_same_update_on_the_gpu():
+    """run.py --fused-adam on CUDA parameters: fused=True is set on the optimizer the reference's constructor call builds, the
+    moments live under the keys the reference's prune / densify surgery indexes, and three steps equal torch's default Adam to
+    float rounding."""
+    import torch
+    from lightgaussian_amd import run as lg_run
+    torch.manual_seed(0)
+    base = [torch.randn(1000, 3, device="cuda:0"), torch.randn(1000, 15, 3, device="cuda:0"), torch.randn(1000, 1, device="cuda:0")]
+    grads = [[torch.randn_like(b) for b in base] for _ in range(3)]
+
+    def run(fused):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        groups = [{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(ps, (1.6e-4, 1.25e-4, 0.05), ("xyz", "f_rest", "opacity"))]
+        if fused:
+            lg_run.fused_adam(True)
+        try:
+            opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        finally:
+            lg_run.fused_adam(False)
+        assert bool(opt.defaults.get("fused")) == fused
+        for g3 in grads:
+            for p, g in zip(ps, g3):
+                p.grad = g.clone()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        st = opt.state[ps[0]]
+        assert "exp_avg" in st and "exp_avg_sq" in st
+        return [p.detach() for p in ps]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)

@@ -37,5 +37,9 @@ import sys, json
 d = json.loads(sys.stdin.read()); print('forced collectives:', d['value'], 'views/s', d.get('data_parallel'), d.get('c4_significance_pass'))" | cut -c1-1500
 timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/finetune_step.py --fused-adam 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/finetune_step.py --n-gaussians 3000000 --iters 40 2>&1 | tail -1 | cut -c1-300
+timeout -s KILL 300 python examples/finetune_step.py --n-gaussians 3000000 --iters 40 --fused-adam 2>&1 | tail -1 | cut -c1-300
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --spatial-order --no-literal
 bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
 bash tools/gpu_profile.sh count 2>&1 | tail -3 | cut -c1-200
