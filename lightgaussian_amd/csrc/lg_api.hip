@@ -342,6 +342,12 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 #undef LAUNCH_FWD
     }
     KCHECK("lg_blend_fwd");
+    // (round 4, measured and rejected -- two ways of letting these kernels share the device through a second HIP stream.  (1) The
+    //  long-tile chain -- work list, lg_tile_sort_long, the two launches below -- on a stream of its own beside lg_blend_fwd, joined by
+    //  events: uniform scene 650 vs 650 views/s fwd+bwd, heavy-tailed 522 -> 528, fwd-only 1585 -> 1553: what the event round trip costs
+    //  is what the three (mostly empty) launches cost, and on the heavy scene the two grids just share the CUs.  (2) Every view's
+    //  lg_blend_fwd<COUNT> on ONE stream, the memory-bound front of up to six views on others: significance pass 1596 vs 1587 views/s
+    //  at four views in flight.  Kernels that each fill the machine do not overlap into max(a, b) here; they add.)
     if (par_long) {
         // persistent grids over the par_work list left by the forward's work-list workgroup (meta[4] items; none on scenes
         // without outlier lists: each launch is then one scalar load per workgroup)
