@@ -72,7 +72,9 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="force the reference's literal getter pattern (torch exp/sigmoid/normalize/cat "
                     "per render call); default: render() evaluates the getters of a reference GaussianModel inside the kernels")
     ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)  # former opt-in flag; now the default behaviour of render()
-    ap.add_argument("--loss", choices=["l1", "l1_torch", "l1_dssim", "l1_dssim_torch"], default="l1",
+    ap.add_argument("--loss-item", action="store_true", help="fwdbwd: loss.item() after every backward, as the reference's trainers do for their running "
+                    "average (prune_finetune.py:168-171): the eager scalar drains the iteration, loss_utils' lazy scalar reads a pinned copy")
+    ap.add_argument("--loss", choices=["l1", "l1_torch", "l1_dssim", "l1_dssim_lazy", "l1_dssim_torch"], default="l1",
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3; HIP lg_loss_forward with LG_FLAG_L1_ONLY), l1_torch (the same "
                          "in torch ops), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
@@ -313,6 +315,15 @@ def main():
         if args.loss == "l1_dssim":
             from lightgaussian_amd import loss_utils
             return loss_utils.l1_dssim_loss(image, gt, 0.2)[0]
+        if args.loss == "l1_dssim_lazy":
+            # the reference's two calls and its formula, literally (prune_finetune.py:161-164), on loss_utils' lazy scalars (set_lazy)
+            from lightgaussian_amd import loss_utils
+            prev = loss_utils.set_lazy(True)
+            try:
+                Ll1 = loss_utils.l1_loss(image, gt)
+                return (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - loss_utils.ssim(image, gt))
+            finally:
+                loss_utils.set_lazy(prev)
         return 0.8 * (image - gt).abs().mean() + 0.2 * (1.0 - torch_ssim(image, gt))
 
     multi = world > 1 or (args.force_collectives and dist.is_initialized())
@@ -340,6 +351,8 @@ def main():
             pkg = render(cams[k], pc, pipe, bg)
             loss = photometric(pkg["render"], gts[k])
             loss.backward()
+            if args.loss_item:
+                loss.item()
             if collectives and dp_step:     # (the rank-0-only measurement legs below must not enter a collective)
                 exchange(params, pkg["visibility_filter"])
         elif args.mode == "fwd":
@@ -591,6 +604,7 @@ def main():
                                   "torch per call (reference's literal getter pattern, --no-fuse)" if args.no_fuse else
                                   "render() evaluates the reference GaussianModel's getters inside K1/K9 (fuse_getters, DESIGN 10)",
                        "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
+                                "l1_dssim_lazy": "0.8*L1 + 0.2*(1-SSIM), fused HIP kernels, the reference's two calls + formula on lazy scalars (loss_utils.set_lazy)",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
                        "parallelism": (f"dp{world}: one camera per rank per step, gradients averaged over RCCL before the next step" if dp_step else
                                        f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},

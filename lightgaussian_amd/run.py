@@ -10,6 +10,12 @@
          other than 0 write under <model_path>/.rank<r>)
     python -m lightgaussian_amd.run --fused-adam /path/to/prune_finetune.py ...
         (opt-in, outside the replaced path: torch.optim.Adam as the trainers construct it, but with fused=True -- fused_adam() below)
+    python -m lightgaussian_amd.run --lazy-loss /path/to/prune_finetune.py ...
+        (opt-in: l1_loss() / ssim() return lazy scalars, loss_utils.LazyLoss -- the trainers' `(1 - lambda) * Ll1 + lambda * (1 - ssim)`
+         line launches nothing, backward() feeds the two coefficients to the fused loss node, loss.item() reads a pinned copy;
+         the trainers' iter_start.elapsed_time(iter_end) then waits for its end event itself -- event_timing() below)
+    python -m lightgaussian_amd.run --no-iter-timing /path/to/prune_finetune.py ...
+        (implies --lazy-loss; elapsed_time of an unfinished pair returns NaN instead of waiting: the host runs ahead of the device)
 
 Why a runner.  The trainers import their collaborators by name from their own directory, which Python puts first on sys.path:
     from utils.loss_utils import l1_loss, ssim                 prune_finetune.py:15, distill_train.py:15, train_densify_prune.py
@@ -280,6 +286,43 @@ def fused_adam(enable=True):
         torch.optim.Adam.__init__ = _ADAM_INIT.pop("orig")
 
 
+_EVENT_ELAPSED = {}
+
+
+def event_timing(mode):
+    """What `iter_start.elapsed_time(iter_end)` does when iter_end has not completed yet.  All three trainers evaluate it every
+    iteration as an argument of training_report (prune_finetune.py:206, distill_train.py:161, train_densify_prune.py:162), right behind
+    the loss.item() of their running average -- which, eagerly, has drained the device by then.  With --lazy-loss item() no longer
+    waits for the backward, and torch raises "Both events must be completed before calculating elapsed time".
+      "wait"  the call waits for its end event first: the trainers' timing stays what it was, the iteration is drained one line later
+              than before (what --lazy-loss then saves is the ten tiny launches of the loss arithmetic)
+      "skip"  (--no-iter-timing) an unfinished pair returns NaN instead of waiting: the host runs ahead of the device like a loop
+              without the logging would (the tensorboard scalar `iter_time` becomes NaN); with it a trainer iteration of the bench
+              (render + L1/D-SSIM + backward, loss.item() per iteration) goes from 1.77-1.85 ms to 1.54 ms
+      None    torch's own method again"""
+    import torch
+    if mode is None:
+        if "orig" in _EVENT_ELAPSED:
+            torch.cuda.Event.elapsed_time = _EVENT_ELAPSED.pop("orig")
+        _EVENT_ELAPSED.pop("mode", None)
+        return
+    if mode not in ("wait", "skip"):
+        raise ValueError("event_timing: mode is 'wait', 'skip' or None")
+    _EVENT_ELAPSED["mode"] = mode
+    if "orig" not in _EVENT_ELAPSED:
+        orig = torch.cuda.Event.elapsed_time
+        _EVENT_ELAPSED["orig"] = orig
+
+        def elapsed_time(self, end_event):
+            if not end_event.query():
+                if _EVENT_ELAPSED.get("mode") == "skip":
+                    return float("nan")
+                end_event.synchronize()
+            return orig(self, end_event)
+
+        torch.cuda.Event.elapsed_time = elapsed_time
+
+
 def _redirect_model_path(argv, rank):
     """Ranks other than 0 of a data-parallel run write their outputs (cfg_args, point clouds, checkpoints, imp_score.npz: the
     trainers write them unconditionally) under <model_path>/.rank<r> instead of on top of rank 0's files.  -m / --model_path is
@@ -298,7 +341,7 @@ def _redirect_model_path(argv, rank):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    distributed = no_patch = verbose = adam = False
+    distributed = no_patch = verbose = adam = lazy = no_timing = False
     backend = "nccl"
     while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
         flag = argv.pop(0)
@@ -310,10 +353,14 @@ def main(argv=None):
             verbose = True
         elif flag == "--fused-adam":
             adam = True
+        elif flag == "--lazy-loss":
+            lazy = True
+        elif flag == "--no-iter-timing":
+            lazy = no_timing = True
         elif flag.startswith("--backend="):       # gloo: CPU tests of the launcher with a stand-in trainer (the rasterizer has no CPU path)
             backend = flag.split("=", 1)[1]
         else:
-            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose --fused-adam, then the script and ITS arguments)")
+            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose --fused-adam --lazy-loss --no-iter-timing, then the script and ITS arguments)")
     if not argv:
         raise SystemExit(__doc__)
     script = os.path.abspath(argv[0])
@@ -350,6 +397,12 @@ def main(argv=None):
                 dist.init_process_group(backend)
     if adam:
         fused_adam(True)
+    if lazy:
+        # l1_loss() / ssim() hand out lazy scalars (loss_utils.LazyLoss): the trainers' loss line costs no kernels and their
+        # per-iteration loss.item() does not wait for the backward.  This (main) thread only; the trainers are single-threaded.
+        from . import loss_utils as _lu
+        _lu.set_lazy(True)
+        event_timing("skip" if no_timing else "wait")
     if not no_patch:
         # --distributed is DATA-PARALLEL training (lightgaussian_amd.dp): a camera shard per rank, the gradients averaged over the
         # ranks in front of every optimizer.step(), prune_list sharded by camera; the ranks stay bit-identical replicas of one model
@@ -360,6 +413,8 @@ def main(argv=None):
     try:
         runpy.run_path(script, run_name="__main__")
     finally:
+        if lazy:
+            event_timing(None)
         if adam:
             fused_adam(False)
         if distributed:

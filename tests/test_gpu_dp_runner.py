@@ -88,7 +88,10 @@ gaussians = make_model(); scene = Scene(); gaussians.training_setup(None)
 pipe, background = syn.PipelineParams(), torch.zeros(3, device="cuda")
 gts = {{c.uid: torch.rand(3, {H}, {W}, generator=torch.Generator().manual_seed(100 + c.uid)).cuda() for c in scene._lg_all_train_cameras()}} if hasattr(scene, "_lg_all_train_cameras") else None
 viewpoint_stack, picked = None, []
-for iteration in range(1, {STEPS} + 1):                     # prune_finetune.py:141-168,287-289
+iter_start, iter_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # prune_finetune.py:90-91
+ema_loss_for_log, timings, kinds = 0.0, [], set()
+for iteration in range(1, {STEPS} + 1):                     # prune_finetune.py:133-172,206,287-289
+    iter_start.record()
     if not viewpoint_stack:
         viewpoint_stack = scene.getTrainCameras().copy()
     viewpoint_cam = viewpoint_stack.pop(randint(0, len(viewpoint_stack) - 1))
@@ -99,7 +102,12 @@ for iteration in range(1, {STEPS} + 1):                     # prune_finetune.py:
     Ll1 = l1_loss(image, gt_image)
     loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim(image, gt_image))
     loss.backward()
+    iter_end.record()
+    kinds.add(type(loss).__name__)
     with torch.no_grad():
+        ema_loss_for_log = 0.4 * loss.item() + 0.6 * ema_loss_for_log          # prune_finetune.py:172
+        timings.append(iter_start.elapsed_time(iter_end))                      # :206, an argument of training_report
+        assert Ll1.item() >= 0.0                                               # training_report: tb_writer.add_scalar(..., Ll1.item(), ...)
         gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
 from lightgaussian_amd import dp
@@ -107,11 +115,15 @@ import torch.distributed as dist
 out = os.environ["LG_TEST_OUT"]
 torch.save({{n: getattr(gaussians, n).detach().cpu() for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}}, os.path.join(out, "params.pt"))
 json.dump(dict(picked=picked, stats=dp.stats(), world=dist.get_world_size() if dist.is_initialized() else 0, backend=dist.get_backend() if dist.is_initialized() else None,
-               render=render.__module__, wrapped=hasattr(render, "__wrapped__"), argv=sys.argv[1:], ncams=len(scene.getTrainCameras())), open(os.path.join(out, "rec.json"), "w"))
+               render=render.__module__, wrapped=hasattr(render, "__wrapped__"), argv=sys.argv[1:], ncams=len(scene.getTrainCameras()),
+               ema=ema_loss_for_log, timings=[t if t == t else None for t in timings], kinds=sorted(kinds)), open(os.path.join(out, "rec.json"), "w"))
 '''
 
 
-def test_three_iterations_through_the_distributed_runner_equal_the_in_process_loop(tmp_path):
+@pytest.mark.parametrize("flags", [[], ["--no-iter-timing"]], ids=["eager-loss", "lazy-loss"])
+def test_three_iterations_through_the_distributed_runner_equal_the_in_process_loop(tmp_path, flags):
+    """flags = --no-iter-timing (implies --lazy-loss): the trainer's loss line runs on lazy scalars, its per-iteration loss.item() reads
+    the pinned copy, its iter_start.elapsed_time(iter_end) does not wait -- and the parameters after three Adam steps are the same bits."""
     root = tmp_path / "LightGaussian"
     for d in ("gaussian_renderer", "utils", "scene"):
         (root / d).mkdir(parents=True)
@@ -128,11 +140,14 @@ def test_three_iterations_through_the_distributed_runner_equal_the_in_process_lo
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        "-m", "lightgaussian_amd.run", "--distributed", str(root / "trainer.py"), "-m", "out"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+                        "-m", "lightgaussian_amd.run", "--distributed"] + flags + [str(root / "trainer.py"), "-m", "out"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert r.returncode == 0, "\n".join(l for l in r.stderr.splitlines() if "rank0" in l or "Error" in l or "error" in l)[-3000:]
     rec = json.load(open(tmp_path / "rec.json"))
     assert rec["world"] == 1 and rec["backend"] == "nccl" and rec["render"] == "lightgaussian_amd.gaussian_renderer" and rec["wrapped"]
     assert rec["argv"] == ["-m", "out"] and rec["ncams"] == NCAM
+    assert rec["kinds"] == (["LazyLoss"] if flags else ["Tensor"]) and 0.0 < rec["ema"] < 1.0 and len(rec["timings"]) == STEPS
+    if not flags:
+        assert all(t is not None and t > 0.0 for t in rec["timings"])       # eager: loss.item() has drained the iteration, the pair is timed
     st = rec["stats"]
     assert st["steps"] == STEPS and st["dense_steps"] == 0 and 0 < st["rows_exchanged"] <= STEPS * N     # the visible-rows path, through RCCL
     got = torch.load(tmp_path / "params.pt")

@@ -140,3 +140,85 @@ def test_repeated_backward_recomputes_and_general_ssim_arguments():
     for i in range(2):
         assert float(per_image[i]) == pytest.approx(float(LU.ssim(xb[i], yb[i])), rel=1e-5)
     assert float(LU.ssim(xb[0], yb[0], window_size=7)) == pytest.approx(LO.ssim(xb[0].cpu().numpy(), yb[0].cpu().numpy()), abs=0.05)
+
+
+def test_lazy_loss_scalars_give_the_eager_gradient_bit_for_bit():
+    """loss_utils.set_lazy (run.py --lazy-loss): the reference's two calls and its formula on LazyLoss scalars -- one fused forward,
+    one fused backward, dL/dimage bit-identical to the eager formula, item() from the pinned copy equal to the eager value."""
+    from lightgaussian_amd import _lib, rasterizer
+    rng = np.random.default_rng(21)
+    x = rng.random((3, 120, 200), dtype=np.float32); y = rng.random((3, 120, 200), dtype=np.float32)
+    lam = 0.2
+
+    def run(lazy):
+        xt = torch.tensor(x, device=DEV, requires_grad=True); yt = torch.tensor(y, device=DEV)
+        prev = LU.set_lazy(lazy)
+        try:
+            Ll1 = LU.l1_loss(xt, yt)
+            loss = (1.0 - lam) * Ll1 + lam * (1.0 - LU.ssim(xt, yt))
+        finally:
+            LU.set_lazy(prev)
+        assert isinstance(loss, LU.LazyLoss) == lazy and isinstance(Ll1, LU.LazyLoss) == lazy
+        loss.backward()
+        return loss.item(), Ll1.item(), xt.grad.clone()
+
+    rasterizer.set_option("profile", True)
+    try:
+        _lib.profile_reset()
+        lazy = run(True)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        assert prof["loss_fwd"][1] == 1 and prof["loss_bwd"][1] == 1
+    finally:
+        rasterizer.set_option("profile", False)
+        _lib.profile_reset()
+    eager = run(False)
+    assert torch.equal(lazy[2], eager[2])
+    assert lazy[0] == pytest.approx(eager[0], rel=1e-6) and lazy[1] == pytest.approx(eager[1], rel=1e-6)
+    # under no_grad (evaluation) and with a tensor operand: falls back to real tensors, same numbers
+    prev = LU.set_lazy(True)
+    try:
+        with torch.no_grad():
+            xt = torch.tensor(x, device=DEV); yt = torch.tensor(y, device=DEV)
+            v = LU.l1_loss(xt, yt)
+            assert isinstance(v, LU.LazyLoss) and not v.requires_grad
+            assert float(v.mean().double()) == pytest.approx(eager[1], rel=1e-6)       # training_report's use (train_densify_prune.py)
+            assert float(v * torch.tensor(2.0, device=DEV)) == pytest.approx(2 * eager[1], rel=1e-6)
+    finally:
+        LU.set_lazy(prev)
+
+
+def test_event_timing_switch_of_the_runner():
+    """run.py --lazy-loss / --no-iter-timing: the trainers' iter_start.elapsed_time(iter_end) on a pair that has not completed
+    raises in torch; 'wait' waits for the end event, 'skip' returns NaN, None restores torch's method."""
+    import math
+    from lightgaussian_amd import run as lg_run
+    a = torch.randn(4096, 4096, device=DEV)
+    orig = torch.cuda.Event.elapsed_time
+
+    def pair():
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(30):
+            a @ a
+        e.record()
+        return s, e
+
+    s, e = pair()
+    if not e.query():                                   # (a very fast device could have finished already)
+        with pytest.raises(RuntimeError):
+            s.elapsed_time(e)
+    try:
+        lg_run.event_timing("wait")
+        s, e = pair()
+        assert s.elapsed_time(e) > 0.0 and e.query()
+        lg_run.event_timing("skip")
+        s, e = pair()
+        v = s.elapsed_time(e)
+        assert math.isnan(v) or v > 0.0
+        torch.cuda.synchronize()
+        assert s.elapsed_time(e) > 0.0                  # a finished pair is timed as usual
+    finally:
+        lg_run.event_timing(None)
+    assert torch.cuda.Event.elapsed_time is orig
