@@ -19,6 +19,9 @@ run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --sync-free off --no-literal
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --long-tiles serial --no-literal
 run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim_lazy --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim --loss-item --no-literal
+run --n-gaussians 3000000 --mode fwdbwd --steps 60 --loss l1_dssim_lazy --loss-item --no-literal
 run --n-gaussians 3000000 --mode fwdbwd --steps 30 --loss l1_dssim_torch --no-literal
 run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwdbwd --steps 50 --sh-degree 2 --no-literal
 run --n-gaussians 6000000 --width 1600 --height 1060 --mode fwd --steps 50 --sh-degree 3 --no-literal
