@@ -211,7 +211,10 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             // its 180-byte SH row as twelve 16-byte pieces, and with all twenty waves' rows in flight the pieces of one cache line
             // are served by several fetches of that line.  Unused dynamic LDS caps the kernel at 12 waves per CU.
             // (K9 is the opposite: capped below its 13 waves per CU it slows down at once, 0.262 -> 0.283 ms at 11.)
-            const size_t k1_dyn = LG_K1_PAD_LDS;
+            // Only where K1 reads SH rows: the significance-only pass (LG_FLAG_SKIP_COLOR) and precomputed colours have no such reads,
+            // and there the reserved LDS only keeps other views' kernels off the CU (significance pass, A/B on one box: 1605 views/s
+            // with the cap, 1667 without, four views in flight; 1513 / 1590 with one).
+            const size_t k1_dyn = (g->shs && !g->colors_precomp && !(v->flags & LG_FLAG_SKIP_COLOR)) ? LG_K1_PAD_LDS : 0;
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
     lg_preprocess<RAWP, DIR><<<nblk, LG_PP, (DIR) ? k1_dyn : 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
