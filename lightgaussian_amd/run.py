@@ -24,7 +24,7 @@ Why a runner.  The trainers import their collaborators by name from their own di
     from scene import Scene, GaussianModel                     prune_finetune.py:19
 With only PYTHONPATH=<this repo> the `diff_gaussian_rasterization` / `simple_knn` shims resolve, i.e. the rasterizer and the
 kNN are replaced, but everything around them is still the reference's torch code: render() evaluates the getters in torch on
-every call (the literal pattern: 391 views/s instead of 665 at 3 M Gaussians / 1080p, round 4), SSIM is five grouped conv2d (10.8 ms per
+every call (the literal pattern: 378 views/s instead of 664 at 3 M Gaussians / 1080p, round 4), SSIM is five grouped conv2d (10.8 ms per
 step at 1080p, three times the whole render), prune_list walks the views one by one, prune_points runs 21 boolean-index kernels,
 the VecTree search materialises cdist.  patch_reference() imports the reference's modules and REBINDS those symbols -- in
 the modules themselves and in every module that already imported them by name -- to the implementations of this package:
