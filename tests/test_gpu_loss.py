@@ -222,3 +222,18 @@ def test_event_timing_switch_of_the_runner():
     finally:
         lg_run.event_timing(None)
     assert torch.cuda.Event.elapsed_time is orig
+
+
+@pytest.mark.parametrize("shp", [(1, 1, 1), (1, 1, 5), (1, 5, 1), (1, 34, 64), (1, 35, 65), (1, 68, 128), (1, 69, 129), (2, 10, 63), (1, 44, 74),
+                                 (1, 33, 10), (3, 7, 193), (1, 103, 9)])
+def test_strip_kernel_edges_against_the_oracle(shp):
+    """Round 4's strip decomposition (a wave per 64 columns x 34 rows, 5-pixel halo, second pixel of lanes 0..9): images narrower
+    than the halo, exactly one strip / segment, one past it, single rows and columns."""
+    rng = np.random.default_rng(100 + shp[1] * 7 + shp[2])
+    x = rng.random(shp, dtype=np.float32)
+    y = np.clip(x + 0.2 * rng.standard_normal(shp).astype(np.float32), 0, 1).astype(np.float32)
+    l1, loss, g = _run(x, y, 0.2)
+    assert l1 == pytest.approx(LO.l1_loss(x, y), rel=TOL, abs=1e-8)
+    assert loss == pytest.approx(LO.l1_dssim(x, y, 0.2), rel=TOL)
+    ref = LO.l1_dssim_grad(x, y, 0.2)
+    assert np.abs(g - ref).max() <= TOL * np.abs(ref).max()
