@@ -34,7 +34,11 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 5
+/* 6 (round 5): geom buffer layout of round 4 ([N][9] SH direction Jacobian, counters[9]), LG_FLAG_SAVE_SH_JACOBIAN as part of the
+ *    forward / backward contract, lg_debug_* moved to lightgaussian_debug.h (all three shipped under 5 -- ADVICE r4), plus this
+ *    round's additions: lg_backward's rgb_only mode, lg_sh_grad_from_rgb, LG_FLAG_BWD_SPLAT_PARALLEL.
+ * 5 (round 3): stateless library -- segment length and long-tile mode travel in lg_view. */
+#define LG_ABI_VERSION 6
 
 enum {
     LG_OK = 0,
@@ -75,6 +79,10 @@ enum {
                                         Gaussian (36 bytes) in the geom buffer, and lg_backward (which finds a marker word there) does not read
                                         the SH coefficients again: 388 MB less per view at 3 M Gaussians.  Without the flag the backward
                                         works as before.  No effect on any result (same operations in the same order). */
+    LG_FLAG_BWD_SPLAT_PARALLEL = 4096, /* lg_backward, hardware-exp path: run the round-5 PROTOTYPE of the backward blend on the other
+                                          parallel axis (lg_blend_bwd_splat: lane = list entry, pixel state marching through the wave) instead of
+                                          lg_blend_bwd.  Same gradients up to float rounding.  Measured slower on every scene tried;
+                                          kept as a cross-check of the product kernel, never set by default. */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc
@@ -190,6 +198,22 @@ int lg_backward(const lg_view* view, const lg_gaussians* g, const int32_t* radii
                 const void* img, int64_t num_rendered, const float* dL_dcolor, float* dL_dmeans2D, float* dL_dmeans3D,
                 float* dL_dshs, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                 float* dL_dcov3D, float* dL_dshs_rest, void* scratch, void* stream);
+
+/* SH inputs with dL_dshs == NULL and dL_dcolors != NULL ("rgb_only", round 5): lg_backward writes dL/d(rgb) per Gaussian [N,3] -- the
+ * gradient of the colour the SH expansion produced, clamped channels zeroed -- to dL_dcolors INSTEAD of the coefficient gradients
+ * (dL_dshs_rest must be NULL too); dL_dmeans3D still contains the view-direction term.  The coefficient gradient of one view is the
+ * outer product basis(dir) x dRGB; lg_sh_grad_from_rgb rebuilds it (bit for bit what lg_backward would have written), for V views at
+ * once, summed in view order and divided by `divisor`:
+ *     dL_dshs[i][k][c] = ( [accumulate: the value already there +] sum_v basis_k(normalize(means3D[i] - campos[v])) * drgb[v][i][c] ) / divisor
+ * (accumulate != 0 continues a running sum over several calls -- a camera batch per rank; pass divisor 1 until the last call)
+ * A data-parallel trainer exchanges 12 bytes per Gaussian and view (all-gather of dRGB + the camera centres) instead of all-reducing
+ * 12 M bytes (192 at degree 3), and every rank ends with identical bits (lightgaussian_amd.parallel.SHGradExchange).  The reference's
+ * trainers run one process per GPU with no gradient exchange at all (scripts/run_prune_finetune.sh:58-96); its extension has no counterpart.
+ *   drgb: V blocks of [N,3] floats, `view_stride` floats apart; campos [V][3]; dL_dshs [N,M,3], or with dL_dshs_rest != NULL the
+ *   GaussianModel split: dL_dshs = _features_dc gradient [N,1,3], dL_dshs_rest = _features_rest gradient [N,M-1,3]. */
+int lg_sh_grad_from_rgb(int32_t N, int32_t M, int32_t sh_degree, int32_t V, const float* means3D, const float* campos,
+                        const float* drgb, int64_t view_stride, float divisor, int32_t accumulate, float* dL_dshs, float* dL_dshs_rest,
+                        void* stream);
 
 /* lg_backward with the per-Gaussian stage (K9) split into `chunks` launches over consecutive Gaussian ranges.  on_chunk(user,
  * first, count) is called on the HOST right after the launch covering Gaussians [first, first + count) has been enqueued: from

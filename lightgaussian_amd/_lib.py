@@ -23,6 +23,8 @@ FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_
 FLAG_NARROW_KEY, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 FLAG_SAVE_SH_JACOBIAN = 2048
+FLAG_BWD_SPLAT_PARALLEL = 4096
+ABI_VERSION = 6     # include/lightgaussian.h LG_ABI_VERSION this binding was written against (load() refuses another)
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
@@ -31,7 +33,8 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_knn3_mean_dist2", "lg_ordered_sum", "lg_forward_bounded", "lg_select_mask", "lg_compact_scratch_bytes",
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
            "lg_debug_sort_keys", "lg_build_id", "lg_backward_chunked", "lg_debug_activations", "lg_view_status",
-           "lg_debug_sort_orphan", "lg_debug_last_contributor", "lg_debug_tile_lists", "lg_geom_visible_offset"]
+           "lg_debug_sort_orphan", "lg_debug_last_contributor", "lg_debug_tile_lists", "lg_geom_visible_offset",
+           "lg_sh_grad_from_rgb"]
 
 
 class lg_view(C.Structure):
@@ -81,6 +84,10 @@ def load():
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
     lib = C.CDLL(LIB_PATH)
     vp, P = C.c_void_p, C.POINTER
+    lib.lg_abi_version.restype = C.c_int; lib.lg_abi_version.argtypes = []
+    if lib.lg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI {lib.lg_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     lib.lg_geom_bytes.restype = C.c_size_t; lib.lg_geom_bytes.argtypes = [C.c_int32]
     lib.lg_img_bytes.restype = C.c_size_t; lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.lg_binning_bytes.restype = C.c_size_t; lib.lg_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
@@ -107,6 +114,8 @@ def load():
     lib.lg_knn_scratch_bytes.restype = C.c_size_t; lib.lg_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.lg_knn3_mean_dist2.restype = C.c_int
     lib.lg_knn3_mean_dist2.argtypes = [C.c_int32, vp, vp, vp, C.c_uint32, vp]
+    lib.lg_sh_grad_from_rgb.restype = C.c_int
+    lib.lg_sh_grad_from_rgb.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp]
     lib.lg_ordered_sum.restype = C.c_int
     lib.lg_ordered_sum.argtypes = [C.c_int32, C.c_int64, vp, C.c_int64, vp, vp]
     lib.lg_forward_bounded.restype = C.c_int

@@ -431,10 +431,14 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     int rc = check_args(v, g);
     if (rc != LG_OK) return rc;
     if (g->N == 0) return LG_OK;   // empty model: torch hands over NULL pointers for empty tensors, and there is nothing to write
-    if (g->shs_rest && !dL_dshs_rest) return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for shs_rest");
+    // SH inputs without dL_dshs but WITH dL_dcolors: K9's rgb_only mode (dL/d rgb per Gaussian instead of the coefficient gradients;
+    // lg_sh_grad_from_rgb rebuilds them) -- then dL_dshs_rest is not needed either
+    const bool rgb_only = g->shs && !dL_dshs && dL_dcolors;
+    if (g->shs_rest && !dL_dshs_rest && !rgb_only) return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for shs_rest");
+    if (rgb_only && dL_dshs_rest) return fail(LG_ERR_INVALID_ARGUMENT, "dL_dshs_rest without dL_dshs");
     if (!radii || !geom_p || !bin_p || !img_p || !dL_dcolor || !dL_dmeans2D || !dL_dmeans3D || !dL_dopacity || !scratch)
         return fail(LG_ERR_INVALID_ARGUMENT, "missing buffer");
-    if ((g->shs && !dL_dshs) || (g->colors_precomp && !dL_dcolors) || (g->scales && (!dL_dscales || !dL_drotations)) ||
+    if ((g->shs && !dL_dshs && !rgb_only) || (g->colors_precomp && !dL_dcolors) || (g->scales && (!dL_dscales || !dL_drotations)) ||
         (g->cov3D_precomp && !dL_dcov3D))
         return fail(LG_ERR_INVALID_ARGUMENT, "missing gradient output for a provided input");
     hipStream_t stream = (hipStream_t)stream_p;
@@ -455,7 +459,10 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     // buffer by the forward: one extra workgroup of lg_blend_fwd)
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
-        if (fast)
+        if (fast && (v->flags & LG_FLAG_BWD_SPLAT_PARALLEL))
+            lg_blend_bwd_splat<<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
+                                                            img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
+        else if (fast)
             lg_blend_bwd<false><<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
                                                               img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
         else
@@ -481,7 +488,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
         geo.counters, bin.meta, (uint32_t)S, geo.touched, geo.offsets, reinterpret_cast<const float4*>(rows), geo.shjac, dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacity,   \
         dL_dscales, dL_drotations, dL_dcov3D)
             // (the view of a backward is the view of its forward: LG_FLAG_SAVE_SH_JACOBIAN says K1 left the SH direction Jacobians)
-            const bool jac = (v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && dL_dshs;
+            const bool jac = (v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && (dL_dshs || rgb_only);
             if (v->flags & LG_FLAG_RAW_PARAMS) { if (jac) LAUNCH_PPB(true, true); else LAUNCH_PPB(true, false); }
             else { if (jac) LAUNCH_PPB(false, true); else LAUNCH_PPB(false, false); }
 #undef LAUNCH_PPB
@@ -494,7 +501,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
         HIP_TRY(hipMemcpyAsync(&h_seg, bin.meta + 2, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (h_seg != (uint32_t)S) return fail(LG_ERR_INVALID_ARGUMENT, "lg_backward: lg_view.segment_length differs from the forward's (gradients are zero)");
-        if ((v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && dL_dshs) {
+        if ((v->flags & LG_FLAG_SAVE_SH_JACOBIAN) && g->shs && (dL_dshs || rgb_only)) {
             uint32_t h_mark = 0;
             HIP_TRY(hipMemcpyAsync(&h_mark, geo.counters + 9, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -522,6 +529,24 @@ extern "C" int lg_backward_chunked(const lg_view* v, const lg_gaussians* g, cons
 {
     return backward_impl(v, g, radii, geom_p, bin_p, img_p, R, dL_dcolor, dL_dmeans2D, dL_dmeans3D, dL_dshs, dL_dcolors, dL_dopacity,
                          dL_dscales, dL_drotations, dL_dcov3D, dL_dshs_rest, scratch, stream_p, chunks, on_chunk, user);
+}
+
+extern "C" int lg_sh_grad_from_rgb(int32_t N, int32_t M, int32_t sh_degree, int32_t V, const float* means3D, const float* campos,
+                                   const float* drgb, int64_t view_stride, float divisor, int32_t accumulate, float* dL_dshs, float* dL_dshs_rest,
+                                   void* stream_p)
+{
+    if (N < 0 || V < 1 || !(M == 1 || M == 4 || M == 9 || M == 16) || sh_degree < 0 || sh_degree > 3 || (sh_degree + 1) * (sh_degree + 1) > M)
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_sh_grad_from_rgb: N >= 0, V >= 1, M in {1, 4, 9, 16}, (D + 1)^2 <= M required");
+    if (N == 0) return LG_OK;
+    if (!means3D || !campos || !drgb || !dL_dshs || view_stride < 3 * (int64_t)N || !(divisor > 0.0f))
+        return fail(LG_ERR_INVALID_ARGUMENT, "lg_sh_grad_from_rgb: missing buffer, view_stride < 3 N or divisor <= 0");
+    if (dL_dshs_rest && M == 1) dL_dshs_rest = nullptr;     // degree 0: nothing beyond the dc row
+    hipStream_t stream = (hipStream_t)stream_p;
+    lg_sh_grad_from_rgb_kernel<<<(N + LG_PP - 1) / LG_PP, LG_PP, 0, stream>>>(N, M, sh_degree, V, means3D, campos, drgb, (size_t)view_stride, divisor,
+                                                                           accumulate ? 1 : 0, dL_dshs, dL_dshs_rest);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_sh_grad_from_rgb_kernel launch", e);
+    return LG_OK;
 }
 
 extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float* weight, float* score, void* stream_p)

@@ -115,6 +115,40 @@ __device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const
     return contrib;
 }
 
+// The same step with the lanes' `done` state as ONE scalar lane mask (round 5).  fwd_pair carries `done` as a per-lane bool through the
+// pair loop; hipcc lowers a loop-carried i1 by re-merging it with exec on every iteration (s_andn2 + s_and + s_or) on top of the xor for
+// `!done`: 13 scalar instructions per pair step, and the scalar unit -- one per CU, shared by all its waves -- is as busy as the vector
+// units in this kernel (0.53 scalar instructions per CU-cycle; six dummy s_add per step cost 8.3 %).  Here every compare is
+// balloted, the masks are combined as plain 64-bit scalars (s_andn2, s_and, s_xor, s_or: four operations) and the contributing set goes
+// back to a lane predicate through llvm.amdgcn.inverse.ballot, which costs no instruction.  9 scalar instructions per pair step, the
+// vector stream unchanged; every compare is the same compare, so counts, scores and images are bit-identical to fwd_pair (kept above as
+// the cross-check: -DLG_K6_BOOL_DONE builds the old form).  Returns the mask of the lanes the entry contributed to.
+template <bool EXACT, bool COLOR = true>
+__device__ __forceinline__ uint64_t fwd_pair_m(const float4& a, const float4& b, const float4& c, uint64_t& donem, float pxf, float pyf, float& T,
+                                               float& C0, float& C1, float& C2, uint32_t& last, uint32_t rel, float& alpha_out, float& w_out)
+{
+    const float dx = a.x - pxf, dy = a.y - pyf;
+    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+    const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : __expf(power);
+    float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
+    if (!EXACT) alpha = guard_alpha(alpha, b.y, power);
+    const uint64_t okm = (__builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= LG_ALPHA_MIN)) & ~donem;
+    const float test_T = T * (1.0f - alpha);
+    const uint64_t satm = okm & __builtin_amdgcn_ballot_w64(test_T < LG_T_MIN);
+    const uint64_t cm = okm ^ satm;
+    donem |= satm;
+    const bool contrib = __builtin_amdgcn_inverse_ballot_w64(cm);
+    if (COLOR) {
+        const float w = contrib ? alpha * T : 0.0f;
+        C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
+        w_out = w;
+    }
+    T = contrib ? test_T : T;
+    last = contrib ? rel : last;
+    alpha_out = alpha;
+    return cm;
+}
+
 // K6 / K6c: forward blend
 template <bool COUNT, bool FSCORE, bool EXACT, bool COLOR = true>
 __global__ void __launch_bounds__(256)
@@ -157,7 +191,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
+#ifdef LG_K6_BOOL_DONE
     bool done = !inside;
+#else
+    uint64_t donem = ~__builtin_amdgcn_ballot_w64(inside);    // saturated or outside the image: one scalar mask per wave (fwd_pair_m)
+#endif
     // Long list (more than one segment of S entries): leave a checkpoint record per pixel at the end of every segment --
     // {T there, colour accumulated INSIDE the segment (absolute weights alpha T: a sum of non-negative terms, no
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
@@ -181,7 +219,11 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
                 seg++; Cs0 = Cs1 = Cs2 = 0.0f;
             }
+#ifdef LG_K6_BOOL_DONE
             if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
+#else
+            if (~donem == 0ull) break;       // every pixel of this wave is saturated or outside
+#endif
             const uint32_t idx = base + lane;
             bool hit = false;
             float4 r0, r1, r2;
@@ -209,13 +251,18 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             for (uint32_t j = 0; j < nhit; j++) {
                 const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
                 float alpha = 0.0f, Tprev = T, w = 0.0f;
-                const int res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w) ? 1 : 0;
+#ifdef LG_K6_BOOL_DONE
+                const bool res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w);
+                const uint64_t cm = COUNT ? __ballot(res) : 0ull;
+#else
+                const uint64_t cm = fwd_pair_m<EXACT, COLOR>(a, b, c, donem, pxf, pyf, T, C0, C1, C2, last, __float_as_uint(c.y), alpha, w);
+                const bool res = __builtin_amdgcn_inverse_ballot_w64(cm);
+#endif
                 if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
                 if (COUNT) {
-                    const uint64_t cm = __ballot(res == 1);
                     if (lane == j) mycnt = (int)__popcll(cm);
                     if (FSCORE) {
-                        float wv = (res == 1) ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
+                        float wv = res ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
                         wv = wave_sum_to_lane63(wv);
                         const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
                         if (lane == j) myf = tot;
@@ -465,19 +512,19 @@ lg_blend_fwd_rewalk(int W, int H, int gx, int S, const uint2* __restrict__ par_w
             T = st.x; C0 = st.y; C1 = st.z; C2 = st.w;
             last = item.y > 0u ? cl[(size_t)item.y * 256] : 0u;
         }
-        bool dn = !mine;
+        uint64_t dnm = ~__builtin_amdgcn_ballot_w64(mine);              // finished (or not parked here): one scalar mask per wave (fwd_pair_m)
         uint32_t cur = item.y, mynext = item.y;                         // mynext: first segment this pixel did not enter
-        for (; cur < nseg && __ballot(!dn) != 0; cur++) {              // wave-uniform
+        for (; cur < nseg && ~dnm != 0ull; cur++) {                     // wave-uniform
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
             uint32_t ls = 0;
-            const bool entered = !dn;
+            const bool entered = !__builtin_amdgcn_inverse_ballot_w64(dnm);
             const uint32_t lo = cur * (uint32_t)S, hi = min(n, lo + (uint32_t)S);
             lg_walk_block(range.x, lo, hi, entries, gid_mask, rec, (float)wx0, (float)wy0, q0[wave], q1[wave], q2[wave], lane,
                           [&](const float4& a, const float4& b, const float4& c, uint32_t rel) {
                               float alpha = 0.0f, w = 0.0f;
-                              (void)fwd_pair<false, true>(a, b, c, !dn, pxf, pyf, T, s0, s1, s2, dn, ls, rel, alpha, w);
+                              (void)fwd_pair_m<false, true>(a, b, c, dnm, pxf, pyf, T, s0, s1, s2, ls, rel, alpha, w);
                           },
-                          [&]() { return __ballot(!dn) == 0; });
+                          [&]() { return ~dnm == 0ull; });
             if (entered) {
                 C0 += s0; C1 += s1; C2 += s2;
                 last = ls ? ls : last;
@@ -810,6 +857,175 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             dst[0] = o0; dst[1] = o1; dst[2] = o2;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 on the OTHER parallel axis (round 5 prototype, r4 verdict item 2; LG_FLAG_BWD_SPLAT_PARALLEL, hardware-exp path only):
+// lane = list entry, the pixels' state marches through the wave.  One wave per (tile, segment) work item, as lg_blend_bwd.
+// The item's entries are taken back to front in buckets of 64; lane l of a bucket holds entry 64 k + 63 - l in REGISTERS
+// (position, conic, opacity, colour, its 1-based list position and its pre-sort slot) together with its own nine moment sums.
+// The 256 pixels of the tile stream through the lanes: at step t lane l works on pixel (t - l) mod 256 of bucket (t - l) / 256,
+// whose state {T, S = (colour behind) . dL/dC, dL/dC, T_final (bg . dL/dC), last contributor, pixel centre} arrived from lane
+// l - 1 by ONE DPP wave_shr:1 per value; lane 0 is fed from the wave's pixel table in LDS, lane 63 writes {T, S} back for the
+// next bucket -- a rolling pipeline: 256 steps per bucket + 63 to drain the item, no refill between buckets.  A lane that has
+// seen its 256th pixel writes its 48-byte row once (no wave_reduce9_via_lds, no `stage` / `red` LDS, no hit masks, no zeroing of
+// nine partials per entry) and takes the next bucket's entry from a staging row that was loaded ~190 steps earlier.
+// Same per-pair arithmetic as lg_blend_bwd<false> (bwd_pair_fast, the same include / exclude decisions), moments summed over the
+// pixels in stream order instead of sub-block partials + tree: equal up to float rounding, deterministic run to run.
+// COST MODEL, stated before the first measurement: 9 DPP moves + ~42 pair instructions per step, 256 steps per 64
+// entries = ~204 wave-instructions per (tile, splat) instance against lg_blend_bwd's measured 99 (409.8 M / 4.14 M at C3) -- every
+// splat pays for all 256 pixels of the tile, where the sub-block walk evaluates 1.47 blocks of 64.  Kill criterion: slower than
+// 0.52 ms at C3 with parity green.
+#define LG_DPP_WAVE_SHR1 0x138
+__device__ __forceinline__ float lg_march(float feed, float v)
+{
+    // lane l <- lane l - 1; lane 0 (no source lane, bound_ctrl off) keeps `feed`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(feed), __float_as_int(v), LG_DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+
+__global__ void __launch_bounds__(64)
+lg_blend_bwd_splat(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
+                   const uint64_t* __restrict__ entries, uint32_t gid_mask, const uint4* __restrict__ tinfo, const float4* __restrict__ rec,
+                   const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                   const float* __restrict__ dL_dpix, const float4* __restrict__ ckpt, float* __restrict__ part)
+{
+    __shared__ float4 pixA[256];                 // {dL/dC r, g, b, T_final (bg . dL/dC)} per pixel of the tile
+    __shared__ float4 pixB[256];                 // {T, S, last contributor (bits), -}: T and S are rewritten by lane 63 bucket after bucket
+    __shared__ float2 pixC[256];                 // pixel centre
+    __shared__ float4 stg[3][LG_Q];              // the NEXT bucket's entries, one staging row per lane
+    if (blockIdx.x >= meta[0]) return;
+    if (meta[2] != (uint32_t)S) return;
+    const uint2 item = work[blockIdx.x];
+    const int tile = (int)item.x;
+    const uint32_t lane = threadIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)H * W;
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+    const uint32_t n_list = range.y - range.x;
+    if (n_list == 0) return;
+    const uint32_t nseg = (n_list + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t seg_lo = item.y * (uint32_t)S, seg_hi = min(n_list, seg_lo + (uint32_t)S);
+    uint32_t wmax = 0;
+    // ---- pixel table: the start state of lg_blend_bwd (end of the list, or the forward's checkpoints of this segment) ----
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int pxi = tx * LG_TILE + (s & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (s >> 1) * 8 + (int)(lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const size_t pid = (size_t)pyi * W + pxi;
+        const uint32_t pix = ((uint32_t)(s >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(s & 1) * 8u + (lane & 7u);
+        float T = inside ? final_T[pid] : 0.0f;
+        const uint32_t last = inside ? n_contrib[pid] : 0u;
+        const float g0 = inside ? dL_dpix[pid] : 0.0f, g1 = inside ? dL_dpix[HW + pid] : 0.0f, g2 = inside ? dL_dpix[2 * HW + pid] : 0.0f;
+        const float Tfb = T * (bgr * g0 + bgg * g1 + bgb * g2);
+        float Sd = 0.0f;
+        if (item.y + 1u < nseg && inside) {
+            const float4* cr = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256;
+            const float4 here = cr[(size_t)item.y * 256 + pix];
+            float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+            for (uint32_t j = nseg - 1u; j > item.y; j--) {
+                const float4 r = cr[(size_t)j * 256 + pix];
+                b0 += r.y; b1 += r.z; b2 += r.w;
+            }
+            const float inv = 1.0f / here.x;
+            T = here.x;
+            Sd = (b0 * g0 + b1 * g1 + b2 * g2) * inv;
+        }
+        pixA[pix] = make_float4(g0, g1, g2, Tfb);
+        pixB[pix] = make_float4(T, Sd, __uint_as_float(last), 0.0f);
+        pixC[pix] = make_float2((float)pxi, (float)pyi);
+        wmax = max(wmax, last);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    if (wmax > seg_hi) wmax = seg_hi;
+    float4* rows = reinterpret_cast<float4*>(part);
+    const int kb_lo = (int)(seg_lo / LG_Q), kb_top = (int)((seg_hi - 1u) / LG_Q);
+    const int kb_hi = wmax > seg_lo ? (int)((wmax - 1u) / LG_Q) : kb_lo - 1;       // last bucket any pixel reached
+    // buckets nobody reached: zero rows (every list entry owns exactly one row)
+    for (int k = kb_top; k > kb_hi; k--) {
+        const uint32_t e = (uint32_t)k * LG_Q + lane;
+        if (e < seg_hi) {
+            const uint32_t id = (uint32_t)entries[range.x + e] & gid_mask;
+            float4* dst = rows + 3 * (size_t)lg_slot_of(tinfo[id], tx, ty);
+            dst[0] = dst[1] = dst[2] = make_float4(0, 0, 0, 0);
+        }
+    }
+    const int nbk = kb_hi - kb_lo + 1;
+    if (nbk <= 0) return;
+    // entry of this lane in bucket-phase b: list position 64 (kb_hi - b) + 63 - lane (the last entry of the bucket sits in lane 0)
+    auto fetch = [&](int b, float4& r0, float4& r1, float4& r2) {
+        const uint32_t e = (uint32_t)(kb_hi - b) * LG_Q + (63u - lane);
+        r0 = r1 = make_float4(0, 0, 0, 0);
+        r2 = make_float4(0, 0, __uint_as_float(0xFFFFFFFFu), 0);
+        if (e < seg_hi) {
+            const uint32_t id = (uint32_t)entries[range.x + e] & gid_mask;
+            const float4 q0 = rec[LG_REC_F4 * (size_t)id], q1 = rec[LG_REC_F4 * (size_t)id + 1], q2 = rec[LG_REC_F4 * (size_t)id + 2];
+            r0 = q0; r1 = q1;
+            r2 = make_float4(q2.x, __uint_as_float(e + 1u), __uint_as_float(lg_slot_of(tinfo[id], tx, ty)), 0.0f);
+        }
+    };
+    {
+        float4 r0, r1, r2;
+        fetch(0, r0, r1, r2);
+        stg[0][lane] = r0; stg[1][lane] = r1; stg[2][lane] = r2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 ca = make_float4(0, 0, 0, 0), cb = ca;     // this lane's entry: {x, y, ha, nb}, {hc, opacity, c0, c1}
+    float cc2 = 0.0f;
+    uint32_t crel = 0xFFFFFFFFu, cslot = 0xFFFFFFFFu;
+    float4 n0 = ca, n1 = ca, n2 = ca;                  // the bucket after next, between its load and its staging
+    float p[9];
+#pragma unroll
+    for (int v9 = 0; v9 < 9; v9++) p[v9] = 0.0f;
+    float T = 0.0f, Sd = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, Tfb = 0.0f, lastf = 0.0f, pxf = 0.0f, pyf = 0.0f;
+    const int span = nbk * 256;
+    const int steps = span + 63;
+    for (int t = 0; t < steps; t++) {
+        const int v = t - (int)lane;
+        // ---- a lane that has seen all 256 pixels of its entry writes the entry's row and takes the next bucket's entry ----
+        if (v >= 0 && v < span && (v & 255) == 0) {
+            if (cslot != 0xFFFFFFFFu) {
+                float4* dst = rows + 3 * (size_t)cslot;
+                dst[0] = make_float4(p[0], p[1], p[2], p[3]); dst[1] = make_float4(p[4], p[5], p[6], p[7]); dst[2] = make_float4(p[8], 0.0f, 0.0f, 0.0f);
+            }
+            ca = stg[0][lane]; cb = stg[1][lane];
+            const float4 r2 = stg[2][lane];
+            cc2 = r2.x; crel = __float_as_uint(r2.y); cslot = __float_as_uint(r2.z);
+#pragma unroll
+            for (int v9 = 0; v9 < 9; v9++) p[v9] = 0.0f;
+        }
+        // ---- wave-uniform: load the bucket after next once every lane has taken the staged one; stage it just before lane 0 needs it ----
+        const int ph = t & 255, bnext = (t >> 8) + 1;
+        if (ph == 64 && bnext < nbk) fetch(bnext, n0, n1, n2);
+        if (ph == 255 && bnext < nbk) {
+            stg[0][lane] = n0; stg[1][lane] = n1; stg[2][lane] = n2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- the pixels move on by one lane; lane 0 takes pixel t mod 256 from the table (nothing while the pipeline drains) ----
+        const bool feed = t < span;
+        const float4 fa = pixA[ph], fb = pixB[ph];
+        const float2 fc = pixC[ph];
+        T = lg_march(fb.x, T); Sd = lg_march(fb.y, Sd);
+        lastf = lg_march(feed ? fb.z : 0.0f, lastf);
+        g0 = lg_march(fa.x, g0); g1 = lg_march(fa.y, g1); g2 = lg_march(fa.z, g2); Tfb = lg_march(fa.w, Tfb);
+        pxf = lg_march(fc.x, pxf); pyf = lg_march(fc.y, pyf);
+        (void)bwd_pair_fast(ca, cb, make_float4(cc2, 0.0f, 0.0f, 0.0f), crel <= __float_as_uint(lastf), pxf, pyf, T, Tfb, g0, g1, g2, Sd, p);
+        // ---- lane 63 is the last entry of the bucket (front-most): its pixel's {T, S} go back to the table for the next bucket ----
+        if (lane == 63u && v >= 0 && v < span) {
+            float2* dst = reinterpret_cast<float2*>(&pixB[v & 255]);
+            *dst = make_float2(T, Sd);
+        }
+    }
+    if (cslot != 0xFFFFFFFFu) {
+        float4* dst = rows + 3 * (size_t)cslot;
+        dst[0] = make_float4(p[0], p[1], p[2], p[3]); dst[1] = make_float4(p[4], p[5], p[6], p[7]); dst[2] = make_float4(p[8], 0.0f, 0.0f, 0.0f);
     }
 }
 

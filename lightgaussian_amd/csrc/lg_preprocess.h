@@ -294,7 +294,12 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
     const bool split = RAW && shs_rest != nullptr;
     const int rowf = split ? 3 * (M - 1) : 3 * M;
     const int rows = min(LG_PP, N - i0);
-    const bool use_sh = (shs != nullptr) && (dL_dshs != nullptr);
+    // rgb_only (round 5, data-parallel steps): SH inputs, but the caller asked for dL/d(rgb) per Gaussian [N,3] (post clamp mask, through
+    // dL_dcolors) INSTEAD of the (M, 3) coefficient gradients -- the SH gradient of one view is the outer product basis(dir) x dRGB, which
+    // every rank can rebuild from 12 bytes per Gaussian and the view's camera centre (lg_sh_grad_from_rgb below): 192 bytes per Gaussian
+    // less to write here and to put on the wire.  The view-direction term of dL/dmeans3D is computed as always.
+    const bool rgb_only = (shs != nullptr) && (dL_dshs == nullptr) && (dL_dcolors != nullptr);
+    const bool use_sh = (shs != nullptr) && ((dL_dshs != nullptr) || rgb_only);
     // JAC: the forward left d rgb / d direction of every visible Gaussian (LG_FLAG_SAVE_SH_JACOBIAN; the host instantiates this variant
     // when the view carries the flag): the coefficients are not read at all.  The marker word says the rows of THIS view are there; a
     // backward handed the flag after a forward without it finds no marker and writes zero gradients (LG_FLAG_DEBUG reports it), like
@@ -397,6 +402,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
         } else if (use_sh) {
             const uint32_t cb = __float_as_uint(q2.w) >> LG_ID_BITS;
             float dRGB[3] = { (cb & 1u) ? 0.0f : a[6], (cb & 2u) ? 0.0f : a[7], (cb & 4u) ? 0.0f : a[8] };
+            if (rgb_only) { dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2]; }
             if (JAC) {
                 const float* jr = shjac + 9 * (size_t)i;          // 36-byte rows: dword-aligned 16-byte loads
                 const lg_f4u j0 = reinterpret_cast<const lg_f4u*>(jr)[0], j1 = reinterpret_cast<const lg_f4u*>(jr)[1];
@@ -443,7 +449,7 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
             dop = dop * sg * (1.0f - sg);
         }
     }
-    if (use_sh) {
+    if (use_sh && !rgb_only) {
         // every lane has read its input row: reuse the LDS rows for the gradient rows, then store coalesced.  (HALVES = 2 sends the
         // 64 rows out in two halves through half the LDS -- 6 KB per wave, four waves per SIMD with the 107 VGPRs of the JAC variant
         // instead of three: measured in round 4, 0.2481 / 0.2451 vs 0.2476 / 0.2481 ms, nothing -- the kernel moves 1.25 GB at 5.1 TB/s.
@@ -512,3 +518,91 @@ lg_preprocess_bwd(int N, int first_blk, int M, int D, int W, int H, float tanfov
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Data-parallel steps (round 5; r4 verdict item 4): the SH-coefficient gradient of ONE view is rank one -- dL/dsh[k][c] =
+// basis_k(dir) * dRGB[c] with dir = normalize(xyz - camera centre) -- so a rank need not ship its 12 M bytes per Gaussian: it ships
+// dRGB [N, 3] (K9's rgb_only output) and its camera centre, and every rank rebuilds
+//     dL/dsh[i][k][c] = ( sum over views v, in view order, of  basis_k(dir_v(i)) * dRGB_v[i][c] ) / divisor
+// here.  Each term is evaluated by lg_backward_sh_jac's own expressions (zero Jacobian: the direction path stays in dL/dmeans3D),
+// i.e. bit for bit the value K9 would have written for that view; the terms are then added in view order, so every rank holds the
+// SAME bits whatever the collective's reduction order would have been, and at two ranks the result equals the dense exchange
+// (t0 + t1) / 2 exactly.  One wave per 64 Gaussians; rows leave through LDS as coalesced 16-byte stores like K9's.
+__global__ void __launch_bounds__(LG_PP)
+lg_sh_grad_from_rgb_kernel(int N, int M, int D, int V, const float* __restrict__ means3D, const float* __restrict__ campos,
+                           const float* __restrict__ drgb, size_t view_stride, float divisor, int accumulate, float* __restrict__ dL_dshs,
+                           float* __restrict__ dL_dshs_rest)
+{
+    __shared__ __attribute__((aligned(16))) float sh_rows[LG_PP * LG_SH_MAXF];
+    const uint32_t lane = threadIdx.x;
+    const int i0 = (int)blockIdx.x * LG_PP;
+    const int i = i0 + (int)lane;
+    const bool split = dL_dshs_rest != nullptr;
+    const int rowf = split ? 3 * (M - 1) : 3 * M;
+    const int rows = min(LG_PP, N - i0);
+    float dsh[LG_SH_MAXF];
+#pragma unroll
+    for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = 0.0f;
+    if (accumulate) {
+        // a camera batch per rank: the views of the batch arrive in several calls; this one continues the running sum the previous call
+        // left in the output (rows in through LDS, coalesced, as they leave)
+        if (rowf > 0) {
+            const float* src = (split ? dL_dshs_rest : dL_dshs) + (size_t)i0 * rowf;
+            const int nfl = rows * rowf;
+            for (int f = (int)lane; f < nfl; f += LG_PP) sh_rows[f] = src[f];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float* row = sh_rows + lane * rowf;
+            if (i < N) {
+#pragma unroll
+                for (int k = 0; k < LG_SH_MAXF; k++) {
+                    if (split) { if (k >= 3 && k - 3 < rowf) dsh[k] = row[k - 3]; }
+                    else if (k < rowf) dsh[k] = row[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (split && i < N) { dsh[0] = dL_dshs[3 * (size_t)i]; dsh[1] = dL_dshs[3 * (size_t)i + 1]; dsh[2] = dL_dshs[3 * (size_t)i + 2]; }
+    }
+    if (i < N) {
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        const float J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int v = 0; v < V; v++) {
+            const float* dr = drgb + (size_t)v * view_stride + 3 * (size_t)i;
+            const float dRGB[3] = { dr[0], dr[1], dr[2] };
+            const float cp[3] = { campos[3 * v], campos[3 * v + 1], campos[3 * v + 2] };
+            float dm[3] = {0, 0, 0};
+            if (v == 0 && !accumulate) lg_backward_sh_jac(D, J, px, py, pz, cp, dRGB, dm, [&](int k, int c, float val) { dsh[k * 3 + c] = val; });
+            else lg_backward_sh_jac(D, J, px, py, pz, cp, dRGB, dm, [&](int k, int c, float val) { dsh[k * 3 + c] += val; });
+        }
+        if (divisor != 1.0f) {
+#pragma unroll
+            for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = dsh[k] / divisor;
+        }
+    }
+    if (split && i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }
+    if (rowf <= 0) return;
+    float* row = sh_rows + lane * rowf;
+    if (split) {
+#pragma unroll
+        for (int k = 3; k < LG_SH_MAXF; k++)
+            if (k - 3 < rowf) row[k - 3] = dsh[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < LG_SH_MAXF; k++)
+            if (k < rowf) row[k] = dsh[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* dst = (split ? dL_dshs_rest : dL_dshs) + (size_t)i0 * rowf;
+    const int nfl = rows * rowf;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int nvec = nfl >> 2;
+        for (int q = (int)lane; q < nvec; q += LG_PP) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(sh_rows)[q];
+        for (int f = (nvec << 2) + (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+    } else {
+        for (int f = (int)lane; f < nfl; f += LG_PP) dst[f] = sh_rows[f];
+    }
+}

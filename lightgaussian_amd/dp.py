@@ -11,11 +11,17 @@ Nothing in the trainers is edited; the glue hangs on four methods of the referen
                                              list stays reachable as scene._lg_all_train_cameras() (the significance pass needs it:
                                              every rank must hand prune_list_sharded the same sequence).
     GaussianModel.training_setup             the optimizer it creates (scene/gaussian_model.py:184-217) gets its step() wrapped:
-                                             average the `.grad` of the six parameter groups over the ranks, then step.  Rows no
-                                             rank's camera saw are exactly zero everywhere and are not exchanged
-                                             (parallel.allreduce_gradients_visible: visibility flags MAX-reduced + ONE packed sum all-reduce -- few,
-                                             large collectives for point-to-point xGMI); the visibility comes from the render()
-                                             calls of the step (note_render, installed around the patched gaussian_renderer.render).
+                                             average the gradients of the parameter groups over the ranks, then step.  Round 5: the
+                                             SH-coefficient gradients (192 of the 236 gradient bytes per Gaussian at degree 3) are
+                                             NOT all-reduced: the patched render() makes the rasterizer's backward leave dL/d(rgb)
+                                             per Gaussian (12 B) and all-gathers that plus the camera centre behind K9
+                                             (parallel.RankOneSHExchange); every rank rebuilds sum_ranks basis(dir) (x) dRGB locally
+                                             (lg_sh_grad_from_rgb: the same bits on every rank).  The other four tensors (44 B per
+                                             Gaussian) go through ONE bucketed dense all-reduce (parallel.allreduce_gradients), or --
+                                             with one view per step -- in ranges overlapped with K9 (parallel.OverlappedGradAllReduce
+                                             over lg_backward_chunked).  The round-4 form (dense SH gradients; only the rows some
+                                             rank's camera saw: parallel.allreduce_gradients_visible) stays as the checker
+                                             (LG_DP_SH=dense, LG_DP_DENSE / visibility from note_render).
     GaussianModel.add_densification_stats    (train_densify_prune.py:175) the per-view statistics are summed over the ranks, so
                                              xyz_gradient_accum / denom -- and with them every densification decision -- are the same
                                              on every rank.
@@ -37,7 +43,19 @@ import torch.distributed as dist
 
 from . import parallel
 
-_STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(), "steps": 0, "rows": 0, "dense_steps": 0}
+_STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(), "steps": 0, "rows": 0, "dense_steps": 0,
+          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0}
+# optimizer group name (scene/gaussian_model.py:204-211) -> attribute the fused rasterizer reports its gradient under
+_GROUP_OF = {"_xyz": "xyz", "_features_dc": "f_dc", "_features_rest": "f_rest", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
+
+
+def sh_mode():
+    """"rank1" (default): SH gradients through parallel.RankOneSHExchange; "dense" (LG_DP_SH=dense): all-reduced like the rest."""
+    return "dense" if os.environ.get("LG_DP_SH", "rank1") == "dense" else "rank1"
+
+
+def _forced():
+    return os.environ.get("LG_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def active():
@@ -87,7 +105,18 @@ def note_render(pc, pkg):
 
 def wrap_render(render_fn):
     """render() that also records the visibility for the gradient exchange (same signature, same result)."""
+    import inspect
+    try:
+        sig = inspect.signature(render_fn).parameters
+        takes_options = "options" in sig or any(q.kind is inspect.Parameter.VAR_KEYWORD for q in sig.values())
+    except (TypeError, ValueError):
+        takes_options = False
+
     def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, **kw):
+        # (a render without an `options` parameter -- not ours -- cannot be told about the sink: its step takes the dense / visible-rows path)
+        sink = _sink_for(pc, override_color, pipe) if (takes_options and torch.is_grad_enabled()) else None
+        if sink is not None:
+            kw["options"] = dict(kw.get("options") or {}, sh_grad_sink=sink)
         pkg = render_fn(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, **kw)
         note_render(pc, pkg)
         return pkg
@@ -96,6 +125,54 @@ def wrap_render(render_fn):
     render.__qualname__ = getattr(render_fn, "__qualname__", "render")
     render.__doc__ = render_fn.__doc__
     return render
+
+
+def _sink_for(pc, override_color, pipe):
+    """The RankOneSHExchange collecting this step's dRGB for the model `pc` (keyed by its _xyz tensor), or None when the render does
+    not evaluate SH inside the rasterizer (override_color, convert_SHs_python), the model is not trainable, no exchange will follow,
+    or LG_DP_SH=dense."""
+    if sh_mode() != "rank1" or not (active() or _forced()):
+        return None
+    xyz = getattr(pc, "_xyz", None)
+    if xyz is None or not getattr(xyz, "requires_grad", False) or override_color is not None or getattr(pipe, "convert_SHs_python", False):
+        return None
+    if not isinstance(getattr(pc, "_features_dc", None), torch.Tensor) or not isinstance(getattr(pc, "_features_rest", None), torch.Tensor):
+        return None
+    with _STATE["lock"]:
+        ent = _STATE["sinks"].get(id(xyz))
+        if ent is None or ent[0] is not xyz:
+            ent = _STATE["sinks"][id(xyz)] = (xyz, parallel.RankOneSHExchange(_STATE["group"], average=True, force=_forced()))
+            while len(_STATE["sinks"]) > 8:
+                _STATE["sinks"].pop(next(iter(_STATE["sinks"])))
+        return ent[1]
+
+
+def _take_sink(params):
+    with _STATE["lock"]:
+        for key, (xyz, sink) in list(_STATE["sinks"].items()):
+            if any(xyz is p for p in params):
+                del _STATE["sinks"][key]
+                return sink if sink.views else None
+    return None
+
+
+def _check_same_set(mask_bits, force=False):
+    """Every rank must exchange the same set of parameters (the flat buffers are sized by it).  The set follows from the trainer's
+    iteration logic -- e.g. train_densify_prune.py:194-197 swaps the opacity Parameter in reset_opacity() between backward() and
+    step(), leaving that group without a gradient on EVERY rank -- so it is compared, not assumed: one 16-byte MAX all-reduce of
+    (mask, ~mask) in front of every exchange.  (Every step, not a sampled schedule: a rank whose set changed must not enter a
+    differently sized collective even once -- gloo aborts the process on a size mismatch, RCCL hangs.  ~20-40 us per step on RCCL,
+    unmeasured on hardware; LG_DP_TRUST=1 skips it.)"""
+    if os.environ.get("LG_DP_TRUST", "0") == "1":
+        return
+    group = _STATE["group"]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([mask_bits, (~mask_bits) & 0xFFFF], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), (~int(t[1].item())) & 0xFFFF
+    if hi != mask_bits or lo != mask_bits:
+        raise RuntimeError(f"data-parallel step: the ranks hold gradients for different parameter groups (this rank: mask {mask_bits:#x}, union "
+                           f"{hi:#x}, intersection {lo:#x}); every rank must differentiate the same set of parameters")
 
 
 def _take_visible(params):
@@ -111,40 +188,69 @@ def _take_visible(params):
 
 
 def exchange_gradients(optimizer, check=None, force=False):
-    """Average the gradients of every parameter group of `optimizer` over the ranks (in place).  Visible-rows exchange when the
-    step's renders were seen by note_render (all six tensors have one row per Gaussian), the dense bucketed all-reduce otherwise.
-    check (default: env LG_DP_CHECK=1): verify that rows outside this rank's visibility are exactly zero -- the precondition of
-    the visible-rows exchange; it holds for the reference's photometric losses, not for a regulariser that touches unseen rows.
-    force: exchange at world size 1 too (an initialised group is still required): the RCCL code path on a 1-GPU box."""
+    """Average the gradients of the parameter groups of `optimizer` over the ranks (in place), right before its step().
+
+    Which parameters: those that HAVE a gradient on this rank -- single-process Adam skips a group whose .grad is None, and the
+    reference's own trainer produces that state (train_densify_prune.py:194-197: reset_opacity() replaces the opacity Parameter
+    between backward() and step()) -- plus the two SH groups when this step's renders went through the rank-one exchange
+    (their .grad is None by design: the sink holds dRGB instead).  The set is compared across ranks (_check_same_set).
+    How: SH groups rebuilt from the all-gathered dRGB (parallel.RankOneSHExchange.finish); the others by one bucketed dense
+    all-reduce -- or, when LG_DP_SH=dense and the step's renders were seen by note_render, the round-4 visible-rows exchange of all
+    six (check: verify its precondition -- rows outside this rank's visibility exactly zero -- default every 64th step and under
+    LG_DP_CHECK=1).  force: exchange at world size 1 too (the RCCL code path on a 1-GPU box)."""
     if not (active() or (force and dist.is_available() and dist.is_initialized())):
         return None
-    params = [p for g in optimizer.param_groups for p in g["params"]]
-    missing = [i for i, p in enumerate(params) if p.grad is None]
-    if missing and len(missing) != len(params):
-        raise RuntimeError(f"data-parallel step: parameter groups {missing} have no gradient on this rank while others do; every rank must "
-                           "differentiate the same set of parameters (the flat exchange buffers would differ in size)")
-    if missing:
-        return None
-    vis = _take_visible(params)
-    N = params[0].shape[0]
-    rows_ok = vis is not None and vis.shape[0] == N and all(p.grad.shape[0] == N for p in params)
-    if check is None:
-        check = os.environ.get("LG_DP_CHECK", "0") == "1"
+    groups = [(g.get("name"), p) for g in optimizer.param_groups for p in g["params"]]
+    params = [p for _n, p in groups]
+    sink = _take_sink(params)
+    by_name = {n: p for n, p in groups if n is not None}
+    sh_params = [by_name.get("f_dc"), by_name.get("f_rest")] if sink is not None else []
+    if sink is not None and (sh_params[0] is None or sh_params[1] is None or by_name.get("xyz") is None):
+        raise RuntimeError("data-parallel step: dRGB was collected for a model whose optimizer has no f_dc / f_rest / xyz groups "
+                           "(scene/gaussian_model.py:204-211 names them); use LG_DP_SH=dense")
+    have = [p for p in params if p.grad is not None and not any(p is q for q in sh_params)]
     _STATE["steps"] += 1
-    if rows_ok:
+    mask_bits = sum(1 << i for i, p in enumerate(params[:16]) if p.grad is not None or any(p is q for q in sh_params))
+    _check_same_set(mask_bits, force)
+    vis = _take_visible(params)
+    if not have and sink is None:
+        return None
+    info = {"mode": "dense", "of": int(params[0].shape[0]), "params": len(have) + len(sh_params)}
+    if sink is not None:
+        xyz = by_name["xyz"]
+        M = 1 + int(sh_params[1].shape[1])
+        g_dc, g_rest = sink.finish(xyz, M)
+        sh_params[0].grad = g_dc.view_as(sh_params[0])
+        sh_params[1].grad = g_rest.view_as(sh_params[1])
+        _STATE["sh_steps"] += 1
+        _STATE["wire_bytes"] += sink.bytes_on_wire
+        _STATE["sh_wire_bytes"] += sink.bytes_on_wire
+        info.update(mode="rank1_sh+dense", sh_bytes_on_wire=sink.bytes_on_wire)
+    if not have:
+        return info
+    N = have[0].shape[0]
+    rows_ok = sink is None and vis is not None and vis.shape[0] == N and all(p.grad.shape[0] == N for p in have) and len(have) == len(params)
+    if rows_ok and os.environ.get("LG_DP_DENSE", "0") != "1":
+        if check is None:
+            check = os.environ.get("LG_DP_CHECK", "") == "1" or (os.environ.get("LG_DP_CHECK", "") != "0" and _STATE["steps"] % 64 == 1)
         if check:
             hidden = ~vis.reshape(-1).bool()
-            for p in params:
+            for p in have:
                 if bool((p.grad.reshape(N, -1)[hidden] != 0).any()):
                     raise RuntimeError("data-parallel step: a gradient row of a Gaussian no render of this step saw is non-zero; the "
                                        "visible-rows exchange would leave it unreduced (use LG_DP_DENSE=1)")
-        if os.environ.get("LG_DP_DENSE", "0") != "1":
-            k, _ = parallel.allreduce_gradients_visible(params, vis, group=_STATE["group"], force=force)
-            _STATE["rows"] += k
-            return {"rows": k, "of": N, "mode": "visible"}
+        k, _ = parallel.allreduce_gradients_visible(have, vis, group=_STATE["group"], force=force)
+        _STATE["rows"] += k
+        world = dist.get_world_size(_STATE["group"])
+        _STATE["wire_bytes"] += int(2 * (N + k * sum(p.grad[0].numel() * 4 for p in have)) * (world - 1) / max(world, 1))
+        info.update(mode="visible", rows=k)
+        return info
     _STATE["dense_steps"] += 1
-    n = parallel.allreduce_gradients(params, group=_STATE["group"], force=force)
-    return {"collectives": n, "of": N, "mode": "dense"}
+    info["collectives"] = parallel.allreduce_gradients(have, group=_STATE["group"], force=force)
+    nb = sum(p.grad.numel() * 4 for p in have)
+    world = dist.get_world_size(_STATE["group"])
+    _STATE["wire_bytes"] += int(2 * nb * (world - 1) / max(world, 1))
+    return info
 
 
 def wrap_optimizer(optimizer):
@@ -156,6 +262,13 @@ def wrap_optimizer(optimizer):
     def step(*a, **kw):
         # (LG_DP_FORCE=1: exchange at world size 1 too -- the RCCL code path of a 1-GPU box, tests/test_gpu_dp_runner.py)
         exchange_gradients(optimizer, force=os.environ.get("LG_DP_FORCE", "0") == "1")
+        with _STATE["lock"]:
+            # visibility / dRGB recorded for models that are never stepped, or whose _xyz was replaced by a prune / densify between
+            # backward() and step(): do not keep the old tensors alive
+            live = {id(p) for g in optimizer.param_groups for p in g["params"]}
+            for store in (_STATE["visible"], _STATE["sinks"]):
+                for key in [k for k in store if k not in live and len(store) > 4]:
+                    store.pop(key, None)
         return inner(*a, **kw)
 
     optimizer.step = step
@@ -209,7 +322,13 @@ def install(gaussian_model_cls=None, scene_cls=None, group=None):
                 self.denom[update_filter] += 1
                 return
             n = self.xyz_gradient_accum.shape[0]
-            inc = torch.zeros((n, 2), dtype=self.xyz_gradient_accum.dtype, device=self.xyz_gradient_accum.device)
+            # one [N, 2] buffer kept across iterations (r4 verdict: it was allocated anew every step); dense on purpose: the ranks'
+            # update_filters differ, and 8 B per Gaussian is 3 % of what the gradient exchange of the same step moves
+            inc = getattr(self, "_lg_dp_inc", None)
+            if inc is None or inc.shape[0] != n or inc.device != self.xyz_gradient_accum.device:
+                inc = self._lg_dp_inc = torch.zeros((n, 2), dtype=self.xyz_gradient_accum.dtype, device=self.xyz_gradient_accum.device)
+            else:
+                inc.zero_()
             inc[update_filter, 0:1] = torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
             inc[update_filter, 1] = 1
             dist.all_reduce(inc, op=dist.ReduceOp.SUM, group=_STATE["group"])
@@ -245,9 +364,13 @@ def uninstall():
             except AttributeError:
                 pass
     _STATE["visible"].clear()
+    _STATE["sinks"].clear()
     _STATE["group"] = None
 
 
 def stats():
     """Counters of the exchanges so far: steps, rows exchanged (visible mode), steps that fell back to the dense all-reduce."""
-    return {"steps": _STATE["steps"], "rows_exchanged": _STATE["rows"], "dense_steps": _STATE["dense_steps"]}
+    return {"steps": _STATE["steps"], "rows_exchanged": _STATE["rows"], "dense_steps": _STATE["dense_steps"],
+            "rank1_sh_steps": _STATE["sh_steps"], "bytes_on_wire": _STATE["wire_bytes"], "sh_bytes_on_wire": _STATE["sh_wire_bytes"]}
+    # (bytes_on_wire: what a ring moves through this rank -- 2 (w - 1) / w of the payload for an all-reduce, payload x w for the
+    #  all-gather of dRGB (own block sent once, w - 1 blocks received); an estimate from the tensor sizes, not a counter)

@@ -13,7 +13,6 @@ All arithmetic runs in liblightgaussian_hip.so (hand-written gfx950 kernels) thr
 include/lightgaussian.h; torch supplies device memory, the current stream and autograd plumbing.
 """
 import ctypes as C
-import os
 import threading
 from typing import NamedTuple
 
@@ -45,8 +44,10 @@ class GaussianRasterizationSettings(NamedTuple):
 # the defaults: prune_list_sharded, backward_over_views, GraphedStep pass what they need per call / per thread.
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
             "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
-            "segment_length": 0, "long_tiles": "auto"}
-_PER_CALL_ONLY = ("pending", "tag", "status_override")
+            "segment_length": 0, "long_tiles": "auto",
+            # cross-check switches of the tests: never needed in production, never read from the environment
+            "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False}
+_PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink")
 _LONG_TILES = ("serial", "auto", "parallel")
 _tls = threading.local()
 
@@ -83,7 +84,16 @@ def set_option(name, value):
     segment_length: entries per backward segment of a long tile list (0 = the library default 512; tests use 64 / 128);
               travels in lg_view.segment_length, the backward of a view uses the value its forward ran with;
     long_tiles: "serial" | "auto" (default) | "parallel": walk of outlier tile lists in training forwards; "auto" is
-              decided on the device from the view's own list statistics -- no dependence on earlier views."""
+              decided on the device from the view's own list statistics -- no dependence on earlier views;
+    sh_grad_sink (per call / per thread only): an object with .add(drgb [N,3], campos [3], sh_degree) -- the backward of a render
+              with SH inputs then writes dL/d(rgb) per Gaussian (12 B) INSTEAD of the SH-coefficient gradients (12 M B), hands it
+              to the sink right behind K9 on the current stream, and returns None for the coefficient gradients: the caller
+              rebuilds them for all ranks' views at once (parallel.RankOneSHExchange; the data-parallel step of lightgaussian_amd.dp);
+    bwd_splat_parallel: the backward blend on the other parallel axis (round-5 prototype lg_blend_bwd_splat, DESIGN 22.1);
+    sh_jacobian / narrow_key / sort_all_bits / k1_lds: cross-check switches for the tests (K9 re-reads the SH coefficients instead
+              of K1's saved direction Jacobian; the sort key laid out as if 40 bits were available; every key bit through the
+              global radix passes; K1's LDS-staged SH reads).  Options like everything else (r4 verdict: they used to be read
+              from os.environ on every call, where a stray variable in a user's shell would silently change the sort)."""
     if name not in _OPTIONS:
         raise KeyError(name)
     _validate(name, value)
@@ -207,9 +217,10 @@ class _Call:
         N = self.means3D.shape[0] if self.means3D is not None else 0
         M = 0 if self.sh is None else int(self.sh.shape[1]) + (0 if sh_rest is None else int(sh_rest.shape[1]))
         flags = _lib.FLAG_RAW_PARAMS if raw else 0
-        if differentiated and "LG_NO_SH_JACOBIAN" not in os.environ:     # (cross-check switch: K9 reads the SH coefficients as in rounds 1-3)
+        if differentiated and opts["sh_jacobian"]:     # (sh_jacobian=False, cross-check: K9 reads the SH coefficients as in rounds 1-3)
             # a backward will follow: K1 leaves the SH direction Jacobian (36 B per visible Gaussian) so that K9 need not read the
-            # coefficients again (LG_FLAG_SAVE_SH_JACOBIAN; no-grad forwards do not pay the extra write)
+            # coefficients again (LG_FLAG_SAVE_SH_JACOBIAN).  `differentiated` is decided where grad mode is still visible
+            # (_wants_grad below): no-grad forwards -- evaluation, teacher renders, the significance pass -- do not pay the write
             flags |= _lib.FLAG_SAVE_SH_JACOBIAN
         if rs.debug:
             flags |= _lib.FLAG_DEBUG
@@ -220,14 +231,15 @@ class _Call:
         if exact and opts["skip_color_in_count"]:
             flags |= _lib.FLAG_SKIP_COLOR
         flags |= {"serial": _lib.FLAG_LONG_SERIAL, "auto": 0, "parallel": _lib.FLAG_LONG_PARALLEL}[opts["long_tiles"]]
-        # cross-check switches (tests toggle these environment variables at run time)
-        env = os.environ
-        if "LG_NARROW_KEY" in env:
+        # cross-check switches (tests pass them as options)
+        if opts["narrow_key"]:
             flags |= _lib.FLAG_NARROW_KEY
-        if "LG_SORT_ALL_BITS" in env:
+        if opts["sort_all_bits"]:
             flags |= _lib.FLAG_SORT_ALL_BITS
-        if "LG_K1_LDS" in env:
+        if opts["k1_lds"]:
             flags |= _lib.FLAG_K1_LDS
+        if opts["bwd_splat_parallel"]:
+            flags |= _lib.FLAG_BWD_SPLAT_PARALLEL
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
                                  int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags, int(opts["segment_length"]))
@@ -419,12 +431,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         count = bool(rs.f_count)
         opts = resolve_options(options)
         call = _Call(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=count, opts=opts,
-                     differentiated=any(ctx.needs_input_grad))
+                     differentiated=opts.get("differentiated", any(ctx.needs_input_grad)))
         with torch.cuda.device(call.dev):
             color, radii, gcount, score, geom, binning, img, num_rendered = _native_forward(lib, call, rs, count)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.opts = {k: v for k, v in opts.items() if k not in _PER_CALL_ONLY}   # the backward runs with the forward's options
+        ctx.sh_sink = opts.get("sh_grad_sink")
         ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
                    scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
         ctx.save_for_backward(call.means3D, call.sh, call.colors, call.opac, call.scales, call.rots, call.cov, radii,
@@ -456,8 +469,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_means2D = torch.empty((N, 3), **f32)
             g_means3D = torch.empty((N, 3), **f32)
             g_opac = torch.empty((N, 1), **f32)
-            g_sh = torch.empty((N, M, 3), **f32) if call.sh is not None else None
-            g_col = torch.empty((N, 3), **f32) if call.colors is not None else None
+            sink = ctx.sh_sink if call.sh is not None else None
+            g_sh = torch.empty((N, M, 3), **f32) if (call.sh is not None and sink is None) else None
+            g_col = torch.empty((N, 3), **f32) if (call.colors is not None or sink is not None) else None
             g_sc = torch.empty((N, 3), **f32) if call.scales is not None else None
             g_rot = torch.empty((N, 4), **f32) if call.rots is not None else None
             g_cov = torch.empty((N, 6), **f32) if call.cov is not None else None
@@ -466,9 +480,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_means3D),
                                       _ptr(g_sh), _ptr(g_col), _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov), None,
                                       _ptr(scratch), stream),
-                                {k: v for k, v in (("means3D", g_means3D), ("shs", g_sh), ("colors_precomp", g_col), ("opacities", g_opac),
+                                {k: v for k, v in (("means3D", g_means3D), ("shs", g_sh), ("colors_precomp", g_col if call.colors is not None else None), ("opacities", g_opac),
                                                    ("scales", g_sc), ("rotations", g_rot), ("cov3D_precomp", g_cov)) if v is not None})
             _lib.check(rc)
+            if sink is not None:            # rgb_only backward: g_col holds dL/d(rgb of the SH expansion); the coefficient gradients are the sink's business
+                sink.add(g_col, call.cp, int(rs.sh_degree))
+                g_col = None
         had_sh, had_col, had_sc, had_cov = ctx.had
         return (g_means3D, g_means2D, g_sh if had_sh else None, g_col if had_col else None, g_opac,
                 g_sc if had_sc else None, g_rot if had_sc else None, g_cov if had_cov else None, None, None)
@@ -488,12 +505,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise Exception("raw-parameter rasterisation is a training path; use count_render for significance")
         rest = features_rest if (features_rest is not None and features_rest.shape[1] > 0) else None
         call = _Call(rs, xyz, features_dc, None, opacity_logit, log_scales, raw_rotations, None, exact=False, sh_rest=rest, raw=True, opts=opts,
-                     differentiated=any(ctx.needs_input_grad))
+                     differentiated=opts.get("differentiated", any(ctx.needs_input_grad)))
         with torch.cuda.device(call.dev):
             color, radii, _gc, _sc, geom, binning, img, num_rendered = _native_forward(lib, call, rs, False)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.opts = {k: v for k, v in opts.items() if k not in _PER_CALL_ONLY}
+        ctx.sh_sink = opts.get("sh_grad_sink")
         ctx.has_rest = rest is not None
         ctx.rest_shape = None if features_rest is None else tuple(features_rest.shape)
         ctx.save_for_backward(call.means3D, call.sh, call.sh_rest, call.opac, call.scales, call.rots, radii, geom, binning, img)
@@ -521,29 +539,45 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             g_means2D = torch.empty((N, 3), **f32); g_xyz = torch.empty((N, 3), **f32); g_opac = torch.empty((N, 1), **f32)
-            g_dc = torch.empty((N, 1, 3), **f32)
-            g_rest = torch.empty((N, rest.shape[1], 3), **f32) if rest is not None else None
+            sink = ctx.sh_sink
+            g_dc = torch.empty((N, 1, 3), **f32) if sink is None else None
+            g_rest = torch.empty((N, rest.shape[1], 3), **f32) if (rest is not None and sink is None) else None
+            g_rgb = torch.empty((N, 3), **f32) if sink is not None else None
             g_sc = torch.empty((N, 3), **f32); g_rot = torch.empty((N, 4), **f32)
             scratch = torch.empty(lib.lg_backward_scratch_bytes(N, ctx.num_rendered), dtype=torch.uint8, device=dev)
             rc = _call_backward(lib, (C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
-                                      C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_xyz), _ptr(g_dc), None,
+                                      C.c_int64(ctx.num_rendered), _ptr(grad_color), _ptr(g_means2D), _ptr(g_xyz), _ptr(g_dc), _ptr(g_rgb),
                                       _ptr(g_opac), _ptr(g_sc), _ptr(g_rot), None, _ptr(g_rest), _ptr(scratch), stream),
                                 {k: v for k, v in (("_xyz", g_xyz), ("_features_dc", g_dc), ("_features_rest", g_rest), ("_opacity", g_opac),
                                                    ("_scaling", g_sc), ("_rotation", g_rot)) if v is not None})
             _lib.check(rc)
+            if sink is not None:
+                sink.add(g_rgb, call.cp, int(rs.sh_degree))
+                return g_xyz, g_means2D, None, None, g_opac, g_sc, g_rot, None, None
         if g_rest is None and ctx.rest_shape is not None:
             g_rest = torch.zeros(ctx.rest_shape, **f32)
         return g_xyz, g_means2D, g_dc, g_rest, g_opac, g_sc, g_rot, None, None
 
 
+def _wants_grad(options, *tensors):
+    """options + {"differentiated": will a backward follow this forward?}.  Decided HERE, outside Function.forward, where grad mode
+    is still what the caller set: inside forward() autograd has already switched it off, and ctx.needs_input_grad mirrors the
+    inputs' requires_grad even under torch.no_grad() -- every evaluation / teacher / significance render would set
+    LG_FLAG_SAVE_SH_JACOBIAN and write 36 B per visible Gaussian for nothing."""
+    want = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    return dict(options or {}, differentiated=want)
+
+
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations, raster_settings,
                             options=None):
+    options = _wants_grad(options, xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations)
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_logit, log_scales, raw_rotations,
                                         raster_settings, options)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, options=None):
+    options = _wants_grad(options, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, options)
 

@@ -40,7 +40,7 @@ def test_library_built_loads_and_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/lightgaussian.h but not exported"
     lib.lg_abi_version.restype = C.c_int
-    assert lib.lg_abi_version() == 5
+    assert lib.lg_abi_version() == 6
     lib.lg_img_bytes.restype = C.c_size_t
     lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     assert lib.lg_img_bytes(1920, 1080) >= 1920 * 1080 * 8

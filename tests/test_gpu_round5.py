@@ -1,0 +1,199 @@
+"""-m gpu: round-5 kernels against what they replace.
+
+  (a) lg_backward's rgb_only mode + lg_sh_grad_from_rgb (the rank-one SH-gradient exchange of the data-parallel step,
+      parallel.RankOneSHExchange): the coefficient gradients rebuilt from dL/d(rgb) and the camera centre are the SAME BITS K9 writes
+      for that view, every other gradient of the view is untouched, two views summed in view order equal autograd's accumulation,
+      and the exchange object run through RCCL at world size 1 (collectives forced) returns the local result.
+  (b) lg_blend_bwd_splat (LG_FLAG_BWD_SPLAT_PARALLEL: K7 on the other parallel axis -- lane = list entry, pixel state marching
+      through the wave): the gradients of lg_blend_bwd up to float rounding, deterministic run to run, with one-segment lists,
+      multi-segment lists (checkpoints), partial buckets and empty tiles; within the oracle tolerance of test_gpu_parity.
+  (c) the pair step of the forward blend on scalar lane masks (fwd_pair_m): covered by every bit-parity test of the suite (counts,
+      scores, canonical images are compared with the oracle bit for bit); here only the long-tile rewalk, which shares it."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import gpu_common
+from common import syn
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+
+def _scene(N=3000, seed=5, scale=0.03, active=3, stored=3, opm=0.0):
+    g = syn.make_gaussians(N, sh_degree=stored, seed=seed, log_scale_mean=math.log(scale), opacity_mean=opm, extent=(2, 1.2, 2), rest_std=0.2)
+    g.active_sh_degree = active
+    return g
+
+
+class _Sink:
+    def __init__(self):
+        self.views = []
+
+    def add(self, drgb, campos, deg):
+        self.views.append((drgb.clone(), campos.clone(), deg))
+
+
+# ---- (a) -----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "literal"])
+@pytest.mark.parametrize("D", [0, 1, 2, 3])
+def test_sh_gradients_rebuilt_from_drgb_are_the_bits_k9_writes(D, fused):
+    from lightgaussian_amd.gaussian_renderer import render
+    from lightgaussian_amd import parallel
+    dev = torch.device(DEV)
+    W, H = 176, 112
+    g = _scene(active=D)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    gimg = torch.from_numpy(np.random.RandomState(3).randn(3, H, W).astype(np.float32)).to(dev)
+    cam = syn.orbit_camera(1, 7, W, H, radius=5.0).to(dev)
+    res = {}
+    for mode in ("dense", "rgb"):
+        pc = g.to(dev).requires_grad_(True)
+        sink = _Sink() if mode == "rgb" else None
+        opts = {"fuse_getters": fused}
+        if sink is not None:
+            opts["sh_grad_sink"] = sink
+        pkg = render(cam, pc, syn.PipelineParams(), bg, options=opts)
+        (pkg["render"] * gimg).sum().backward()
+        grads = {n: (getattr(pc, n).grad.clone() if getattr(pc, n).grad is not None else None) for n in RAW}
+        if sink is not None:
+            assert len(sink.views) == 1 and grads["_features_dc"] is None and grads["_features_rest"] is None
+            drgb, cp, deg = sink.views[0]
+            assert deg == D and torch.equal(cp.reshape(3), cam.camera_center.reshape(3))
+            g_dc, g_rest = parallel.sh_grad_from_rgb(pc._xyz, cp.reshape(1, 3), drgb.unsqueeze(0), D, 16)
+            grads["_features_dc"], grads["_features_rest"] = g_dc, g_rest
+        res[mode] = (pkg["render"].detach().clone(), grads)
+    assert torch.equal(res["dense"][0], res["rgb"][0])
+    for n in RAW:
+        a, b = res["dense"][1][n], res["rgb"][1][n]
+        assert torch.equal(a, b.view_as(a)), f"{n}: rebuilt from dRGB differs from K9's own rows (D={D}, fused={fused})"
+    assert float(res["dense"][1]["_features_dc"].abs().sum()) > 0
+    if D > 0:
+        assert float(res["dense"][1]["_features_rest"][:, :(D + 1) ** 2 - 1].abs().sum()) > 0
+    assert float(res["dense"][1]["_features_rest"][:, (D + 1) ** 2 - 1:].abs().sum()) == 0.0
+
+
+def test_two_views_summed_in_view_order_equal_the_accumulated_dense_gradient():
+    from lightgaussian_amd.gaussian_renderer import render
+    from lightgaussian_amd import parallel
+    dev = torch.device(DEV)
+    W, H = 160, 96
+    g = _scene(N=4101, seed=9)                       # N not a multiple of 64
+    bg = torch.zeros(3, device=dev)
+    cams = [syn.orbit_camera(k, 7, W, H, radius=5.0).to(dev) for k in (0, 3)]
+    gimgs = [torch.from_numpy(np.random.RandomState(k).randn(3, H, W).astype(np.float32)).to(dev) for k in (1, 2)]
+    pc = g.to(dev).requires_grad_(True)
+    for cam, gi in zip(cams, gimgs):
+        (render(cam, pc, syn.PipelineParams(), bg)["render"] * gi).sum().backward()
+    dense = {n: getattr(pc, n).grad.clone() for n in RAW}
+    ex = parallel.RankOneSHExchange()                # no process group: the views stay local
+    pc2 = g.to(dev).requires_grad_(True)
+    for cam, gi in zip(cams, gimgs):
+        (render(cam, pc2, syn.PipelineParams(), bg, options={"sh_grad_sink": ex})["render"] * gi).sum().backward()
+    g_dc, g_rest = ex.finish(pc2._xyz, 16)
+    assert torch.equal(g_dc, dense["_features_dc"]) and torch.equal(g_rest, dense["_features_rest"])
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        assert torch.equal(getattr(pc2, n).grad, dense[n]), n
+    # one call over both views == two calls with accumulate (what finish() did): V = 2 in one launch
+    drgbs, cps = [], []
+    s = _Sink()
+    pc3 = g.to(dev).requires_grad_(True)
+    for cam, gi in zip(cams, gimgs):
+        (render(cam, pc3, syn.PipelineParams(), bg, options={"sh_grad_sink": s})["render"] * gi).sum().backward()
+    drgb = torch.stack([v[0] for v in s.views]); cp = torch.stack([v[1].reshape(3) for v in s.views])
+    one = parallel.sh_grad_from_rgb(pc3._xyz, cp, drgb, 3, 16, divisor=2.0)
+    assert torch.equal(one[0], dense["_features_dc"] / 2.0) and torch.equal(one[1], dense["_features_rest"] / 2.0)
+
+
+def test_rank_one_exchange_through_rccl_at_world_size_one():
+    """The collective path of RankOneSHExchange (all_gather_into_tensor on a side stream behind K9) on the RCCL backend, forced at
+    world size 1: same gradients as without a process group."""
+    import subprocess
+    import sys
+    code = r'''
+import os, math, sys, torch, numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["LG_ROOT"], "tests")); sys.path.insert(0, os.environ["LG_ROOT"])
+from common import syn
+from lightgaussian_amd.gaussian_renderer import render
+from lightgaussian_amd import parallel
+torch.cuda.set_device(0); dev = torch.device("cuda:0")
+dist.init_process_group("nccl", device_id=dev)
+g = syn.make_gaussians(3000, sh_degree=3, seed=5, log_scale_mean=math.log(0.03), extent=(2, 1.2, 2), rest_std=0.2)
+W, H = 160, 96
+cams = [syn.orbit_camera(k, 7, W, H, radius=5.0).to(dev) for k in (0, 2)]
+bg = torch.zeros(3, device=dev)
+gi = torch.from_numpy(np.random.RandomState(1).randn(3, H, W).astype(np.float32)).to(dev)
+out = []
+for force in (False, True):
+    pc = g.to(dev).requires_grad_(True)
+    ex = parallel.RankOneSHExchange(force=force)
+    for cam in cams:
+        (render(cam, pc, syn.PipelineParams(), bg, options={"sh_grad_sink": ex})["render"] * gi).sum().backward()
+    nbytes = ex.bytes_on_wire
+    out.append(ex.finish(pc._xyz, 16) + (nbytes,))
+assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+assert out[0][2] == 0 and out[1][2] == 2 * (3 * 3000 + 3) * 4
+assert float(out[0][1].abs().sum()) > 0
+dist.destroy_process_group()
+print("RANK1_OK")
+'''
+    env = dict(os.environ, LG_ROOT=common.ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RANK1_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+# ---- (b) -----------------------------------------------------------------------------------------------------------------------
+def _grads(g, cam, W, H, bg, gimg, options, fused=True):
+    from lightgaussian_amd.gaussian_renderer import render
+    dev = torch.device(DEV)
+    pc = g.to(dev).requires_grad_(True)
+    pkg = render(cam.to(dev), pc, syn.PipelineParams(), bg, options=dict(options, fuse_getters=fused))
+    (pkg["render"] * gimg).sum().backward()
+    out = {n: getattr(pc, n).grad.detach().cpu().numpy() for n in RAW}
+    out["means2D"] = pkg["viewspace_points"].grad.detach().cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("case", ["uniform", "segments64", "dense_pile", "tiny"])
+def test_splat_parallel_backward_gives_the_gradients_of_the_pixel_parallel_one(case):
+    dev = torch.device(DEV)
+    cfg = {"uniform": dict(N=6000, W=208, H=144, scale=0.03, opm=0.0, seg=0),
+           "segments64": dict(N=9000, W=160, H=96, scale=0.05, opm=-1.0, seg=64),        # every list of > 64 entries in several segments
+           "dense_pile": dict(N=5000, W=96, H=64, scale=0.12, opm=1.5, seg=128),         # saturating pixels, lists of thousands
+           "tiny": dict(N=70, W=40, H=24, scale=0.05, opm=0.0, seg=0)}[case]              # partial buckets, empty tiles, image edge
+    g = _scene(N=cfg["N"], seed=17, scale=cfg["scale"], opm=cfg["opm"])
+    W, H = cfg["W"], cfg["H"]
+    cam = syn.orbit_camera(2, 7, W, H, radius=5.0)
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    gimg = torch.from_numpy(np.random.RandomState(11).randn(3, H, W).astype(np.float32)).to(dev)
+    base = {"segment_length": cfg["seg"]}
+    a = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=False))
+    b = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=True))
+    b2 = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=True))
+    for n in a:
+        assert np.isfinite(b[n]).all(), n
+        assert np.array_equal(b[n], b2[n]), f"{n}: the splat-parallel backward is not deterministic run to run"
+        scale = np.abs(a[n]).max() + 1e-30
+        assert np.abs(a[n] - b[n]).max() <= 2e-5 * scale, f"{case} {n}: {np.abs(a[n] - b[n]).max() / scale:.3e} of the tensor's scale"
+    assert np.abs(a["_xyz"]).max() > 0
+    # and against the float64 oracle, with the tolerance rule of test_gpu_parity (literal getters: the oracle takes activated tensors)
+    if case in ("uniform", "tiny"):
+        kw = common.scene_kwargs(g, cam, W, H, deg=3, bg=(0.3, 0.2, 0.1), as_torch=True)
+        kwn = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        f64 = oracle.forward(dtype=np.float64, **kwn); g64 = oracle.backward(f64, gimg.cpu().numpy())
+        f32 = oracle.forward(**kwn); g32 = oracle.backward(f32, gimg.cpu().numpy())
+        from lightgaussian_amd import rasterizer
+        with rasterizer.options(bwd_splat_parallel=True, segment_length=cfg["seg"]):
+            hip = gpu_common.hip_forward_backward(kw, grad_image=gimg.cpu().numpy())["grads"]
+        for name, gv in hip.items():
+            floor = gpu_common.rel_err(g32[name], g64[name])
+            err = gpu_common.rel_err(np.asarray(gv).reshape(np.shape(g64[name])), g64[name])
+            assert err <= max(1e-4, 3.0 * floor), f"{case} {name}: {err:.3e} (fp32 oracle floor {floor:.3e})"

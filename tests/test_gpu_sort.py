@@ -121,7 +121,7 @@ def _tile_lists(image, W, H):
 
 def test_two_stage_sort_gives_the_lists_of_the_one_stage_sort_in_every_length_class():
     """Default: radix passes on the tile bits + one LDS counting sort per tile (a wave for lists up to 1024 entries, a workgroup up
-    to 4096, the chunked 1024-thread kernel beyond).  LG_SORT_ALL_BITS=1: every bit through the global radix passes (round 2).
+    to 4096, the chunked 1024-thread kernel beyond).  option sort_all_bits: every bit through the global radix passes (round 2).
     Both must leave the same lists, entry for entry, and every list strictly ascending in (depth, id)."""
     import os
     from lightgaussian_amd import synthetic as syn
@@ -133,14 +133,11 @@ def test_two_stage_sort_gives_the_lists_of_the_one_stage_sort_in_every_length_cl
     pc = g.to(dev).requires_grad_(True)
     cam = syn.orbit_camera(1, 10, W, H).to(dev)
     lists = {}
+    from lightgaussian_amd import rasterizer
     for mode in ("two_stage", "one_stage"):
-        if mode == "one_stage":
-            os.environ["LG_SORT_ALL_BITS"] = "1"
-        try:
+        with rasterizer.options(sort_all_bits=mode == "one_stage"):
             pkg = render(cam, pc, syn.PipelineParams(), torch.zeros(3, device=dev))
             lists[mode] = _tile_lists(pkg["render"], W, H) + (pkg["render"].detach().cpu().numpy(),)
-        finally:
-            os.environ.pop("LG_SORT_ALL_BITS", None)
     (ra, ea, ia), (rb, eb, ib) = lists["two_stage"], lists["one_stage"]
     n = ra[:, 1] - ra[:, 0]
     assert ((n > 1) & (n <= 1024)).any() and ((n > 1024) & (n <= 4096)).any() and (n > 4096).any(), (int(n.max()), np.percentile(n, [50, 90, 99]))

@@ -83,6 +83,9 @@ for t in range(trials):
 from lightgaussian_amd.gaussian_renderer import render_fused, _render_unfused  # noqa: E402
 dev = torch.device("cuda:0")
 bad2 = 0
+if os.environ.get("LG_FUZZ_NARROW"):   # keys laid out as if only 40 bits were available (option narrow_key)
+    from lightgaussian_amd import rasterizer as _r
+    _r.set_option("narrow_key", True)
 n2 = int(os.environ.get("LG_FUZZ_N2", max(10, trials // 4)))   # LG_FUZZ_N2: size of the fused-getter phase on its own
 for t in range(n2):
     rs = np.random.RandomState(991 + 104729 * t)
