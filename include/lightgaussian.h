@@ -73,12 +73,19 @@ enum {
                               Neither flag (default): only lists longer than two segments and four times the view's mean list --
                               decided on the device from this view's own instance count, so the choice never depends on what the
                               process rendered before.  Images of the parallel walk agree with the serial one to float rounding
-                              (regrouped transmittance products), n_contrib exactly; canonical / count forwards are always serial.
+                              (regrouped transmittance products), n_contrib exactly.  Canonical colour forwards, count forwards that return an
+                              image and the float weight policies always walk serially; the significance-only count pass (LG_FLAG_SKIP_COLOR,
+                              integer weights) has a parallel walk of its own since round 5 (lg_count_seg / _rewalk / _fixup), taken ONLY when
+                              LG_FLAG_LONG_PARALLEL is set (measured slower than the serial walk with several views in flight, which is how
+                              the pass runs by default); its counts are bit-identical to the serial walk's.
                               No counterpart in the reference (its renderCUDA walks every list serially). */
     LG_FLAG_SAVE_SH_JACOBIAN = 2048, /* forward: this view will be differentiated -- K1 leaves d rgb / d (view direction) of every visible
                                         Gaussian (36 bytes) in the geom buffer, and lg_backward (which finds a marker word there) does not read
                                         the SH coefficients again: 388 MB less per view at 3 M Gaussians.  Without the flag the backward
                                         works as before.  No effect on any result (same operations in the same order). */
+    LG_FLAG_COUNT_WIDE_BAND = 8192, /* tests only: the parallel long-tile walk of the significance-only pass compares regrouped transmittances with
+                                       the 1e-4 threshold through an error band; this widens the band 4096 x, sending a fifth of the saturating pixels
+                                       through the exact fix-up pass instead of a handful per view.  Counts must not change. */
     LG_FLAG_BWD_SPLAT_PARALLEL = 4096, /* lg_backward, hardware-exp path: run the round-5 PROTOTYPE of the backward blend on the other
                                           parallel axis (lg_blend_bwd_splat: lane = list entry, pixel state marching through the wave) instead of
                                           lg_blend_bwd.  Same gradients up to float rounding.  Measured slower on every scene tried;

@@ -35,6 +35,10 @@ int lg_debug_last_contributor(const lg_view* view, int32_t N, const void* geom, 
 int lg_debug_tile_lists(const lg_view* view, const void* binning, int64_t num_rendered, uint32_t* out_ranges, uint64_t* out_entries,
                         void* stream);
 
+/* diagnostics: the 16 per-view words a forward leaves in its binning buffer (0 = work items of the backward, 1 = longest list, 2 = segment
+ * length, 3 = par_min, 4 = items of the parallel long-tile walk, 5 = pixels the significance pass resolved through its exact fix-up) */
+int lg_debug_view_meta(const lg_view* view, const void* binning, int64_t num_rendered, uint32_t* out_meta16, void* stream);
+
 /* diagnostics: the failure path of the sort's look-back -- one digit pass whose only tile has a predecessor that never publishes.
  * Must return LG_ERR_DEVICE (error word set, no hang, no silent wrong order).  temp: lg_debug_sort_temp_bytes(2 * 8192). */
 int lg_debug_sort_orphan(int64_t n, const uint64_t* keys_in, uint64_t* keys_out, void* temp, void* stream);

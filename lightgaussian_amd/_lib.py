@@ -24,6 +24,7 @@ FLAG_NARROW_KEY, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 FLAG_SAVE_SH_JACOBIAN = 2048
 FLAG_BWD_SPLAT_PARALLEL = 4096
+FLAG_COUNT_WIDE_BAND = 8192
 ABI_VERSION = 6     # include/lightgaussian.h LG_ABI_VERSION this binding was written against (load() refuses another)
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
@@ -34,7 +35,7 @@ EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scr
            "lg_compact_plan", "lg_compact_rows", "lg_vq_scratch_bytes", "lg_vq_nearest", "lg_debug_sort_temp_bytes",
            "lg_debug_sort_keys", "lg_build_id", "lg_backward_chunked", "lg_debug_activations", "lg_view_status",
            "lg_debug_sort_orphan", "lg_debug_last_contributor", "lg_debug_tile_lists", "lg_geom_visible_offset",
-           "lg_sh_grad_from_rgb"]
+           "lg_sh_grad_from_rgb", "lg_debug_view_meta"]
 
 
 class lg_view(C.Structure):
@@ -144,6 +145,7 @@ def load():
     lib.lg_debug_last_contributor.argtypes = [P(lg_view), C.c_int32, vp, vp, vp, C.c_int64, vp, vp]
     lib.lg_debug_sort_orphan.restype = C.c_int; lib.lg_debug_sort_orphan.argtypes = [C.c_int64, vp, vp, vp, vp]
     lib.lg_geom_visible_offset.restype = C.c_size_t; lib.lg_geom_visible_offset.argtypes = [C.c_int32]
+    lib.lg_debug_view_meta.restype = C.c_int; lib.lg_debug_view_meta.argtypes = [P(lg_view), vp, C.c_int64, vp, vp]
     lib.lg_debug_tile_lists.restype = C.c_int; lib.lg_debug_tile_lists.argtypes = [P(lg_view), vp, C.c_int64, vp, vp, vp]
     lib.lg_profile_read.restype = C.c_int; lib.lg_profile_read.argtypes = [P(lg_kernel_time), C.c_int]
     lib.lg_profile_reset.restype = None; lib.lg_profile_reset.argtypes = []

@@ -322,14 +322,23 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     // from this view's own instance count (lg_par_min, lg_binning.h) -- no history, no host hint: two renders of the same
     // inputs run the same kernels on the same lists whatever the process rendered before.  LG_FLAG_LONG_SERIAL / _PARALLEL
     // override the default rule per call; the canonical / count variants always walk serially (bit-pinned).
-    const int long_mode = (!count && fast && cap > 0 && N > 0) ? ((v->flags & LG_FLAG_LONG_SERIAL) ? 0 : (v->flags & LG_FLAG_LONG_PARALLEL) ? 2 : 1) : 0;
+    // Round 5: the significance-only pass (count forward, canonical arithmetic, no colour, integer weights) has a parallel long-tile walk
+    // of its own (lg_count_seg / _rewalk / _fixup: bit-identical counts through interval comparisons + an exact fix-up); count forwards
+    // that return an image and the float weight policies walk serially.
+    const bool cnt_par = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR) && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY);
+    // The default rule ("auto") applies to the colour forward only.  For the significance pass it was measured and lost (heavy-tailed scene,
+    // four views in flight as prune_list_sharded runs them: 1150 views/s against 1497 serial): the serial walk of a pile stops
+    // early in every wave whose pixels saturate, the parallel one walks every segment twice, and with other views in flight the device is
+    // never idle behind the one long walk -- total work decides, not the critical path.  LG_FLAG_LONG_PARALLEL selects it explicitly.
+    const int long_mode = (!count && fast && cap > 0 && N > 0) ? ((v->flags & LG_FLAG_LONG_SERIAL) ? 0 : (v->flags & LG_FLAG_LONG_PARALLEL) ? 2 : 1)
+                        : (cnt_par && cap > 0 && N > 0 && (v->flags & LG_FLAG_LONG_PARALLEL)) ? 2 : 0;
     const bool par_long = long_mode != 0;
     {
         ProfScope ps(prof, count ? "blend_fwd_count" : "blend_fwd", stream);
         // + 1: the last workgroup builds the backward's work list from the tile ranges (colour forwards only: the
         // significance-only pass has no backward)
         const bool nocolor_pass = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);
-        dim3 grid(ntiles_pad + (nocolor_pass ? 0 : 1)), block(256);
+        dim3 grid(ntiles_pad + ((nocolor_pass && !par_long) ? 0 : 1)), block(256);     // (the parallel long-tile walk needs the par_work list)
 #define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
     lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
                                                          out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived)
@@ -351,7 +360,15 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     //  is what the three (mostly empty) launches cost, and on the heavy scene the two grids just share the CUs.  (2) Every view's
     //  lg_blend_fwd<COUNT> on ONE stream, the memory-bound front of up to six views on others: significance pass 1596 vs 1587 views/s
     //  at four views in flight.  Kernels that each fill the machine do not overlap into max(a, b) here; they add.)
-    if (par_long) {
+    if (par_long && cnt_par) {
+        ProfScope ps(prof, "blend_fwd_count_long", stream);
+        const uint32_t pgrid = (uint32_t)std::min<int64_t>((int64_t)ntiles + cap / S + 1, LG_PAR_GRID);
+        const float band_mul = (v->flags & LG_FLAG_COUNT_WIDE_BAND) ? 4096.0f : 1.0f;
+        lg_count_seg<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt, bin.ckpt_last, bin.par_arrived, band_mul);
+        lg_count_rewalk<<<pgrid, 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt, bin.ckpt_last, out_count, band_mul);
+        lg_count_fixup<<<std::min<uint32_t>(pgrid, 256u), 256, 0, stream>>>(W, H, gx, S, bin.par_work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.rec, bin.ckpt_last, out_count);
+        KCHECK("lg_count_long");
+    } else if (par_long) {
         // persistent grids over the par_work list left by the forward's work-list workgroup (meta[4] items; none on scenes
         // without outlier lists: each launch is then one scalar load per workgroup)
         ProfScope ps(prof, "blend_fwd_long", stream);
@@ -744,7 +761,8 @@ extern "C" int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_di
         HIP_TRY(lg_sort_keys(kv.sort_temp, tb, kv.pairs_in, kv.pairs_out, (uint32_t)P, 32, 32 + key_bits, nullptr, false, stream));
         HIP_TRY(hipMemsetAsync(kv.cell_start, 0, (size_t)kv.cap * 4, stream));
         HIP_TRY(hipMemsetAsync(kv.cell_end, 0, (size_t)kv.cap * 4, stream));
-        lg_knn_ranges<<<nb, 256, 0, stream>>>(P, points, kv.pairs_out, kv.cell_start, kv.cell_end, kv.sorted);
+        lg_knn_ranges<<<nb, 256, 0, stream>>>(P, points, kv.pairs_out, kv.cell_start, kv.cell_end, kv.sorted,
+                                              (const uint32_t*)((char*)kv.sort_temp + lg_sort_layout((size_t)P).ticket_off) + 15, kv.box);
         KCHECK("lg_knn_ranges");
         uint32_t* open_in = (level & 1) ? kv.open_a : kv.open_b;
         uint32_t* open_out = (level & 1) ? kv.open_b : kv.open_a;
@@ -753,6 +771,11 @@ extern "C" int lg_knn3_mean_dist2(int32_t P, const float* points, float* mean_di
                                              kv.box + 8 + (level > 0 ? level - 1 : 0), open_out, kv.box + 8 + level, mean_dist2);
         KCHECK("lg_knn_query");
     }
+    // one 4-byte read-back at the end (distCUDA2 runs once per training run, scene/gaussian_model.py:152): did any level's sort give up?
+    uint32_t h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, kv.box + 15, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h_err) return fail(LG_ERR_DEVICE, "lg_knn3_mean_dist2: the radix sort of a grid level gave up (look-back poll budget exhausted): the distances are void");
     return LG_OK;
 }
 
@@ -841,6 +864,15 @@ extern "C" int lg_debug_tile_lists(const lg_view* v, const void* bin_p, int64_t 
     hipError_t e = hipMemcpyAsync(out_ranges, bin.ranges, ntiles * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream_p);
     if (e == hipSuccess && R > 0) e = hipMemcpyAsync(out_entries, bin.entries, (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream_p);
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_tile_lists copy", e);
+    return LG_OK;
+}
+
+extern "C" int lg_debug_view_meta(const lg_view* v, const void* bin_p, int64_t R, uint32_t* out_meta16, void* stream_p)
+{
+    if (!v || !bin_p || !out_meta16 || R < 0 || v->image_width <= 0 || v->image_height <= 0) return fail(LG_ERR_INVALID_ARGUMENT, "lg_debug_view_meta: missing buffer");
+    BinView bin = carve_bin(const_cast<void*>(bin_p), R, v->image_width, v->image_height, lg_segment_of(v));
+    hipError_t e = hipMemcpyAsync(out_meta16, bin.meta, 64, hipMemcpyDeviceToDevice, (hipStream_t)stream_p);
+    if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_debug_view_meta copy", e);
     return LG_OK;
 }
 

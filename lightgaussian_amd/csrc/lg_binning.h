@@ -859,6 +859,7 @@ __device__ __forceinline__ void lg_work_order_body(int T, int S, const uint2* __
         meta[1] = base[256];                                    // longest list of the view
         meta[2] = (uint32_t)S;                                  // checked by the backward (lg_blend_bwd, lg_preprocess_bwd)
         meta[3] = par_min;
+        meta[5] = 0u;                                           // pixels resolved by lg_count_fixup (diagnostics, lg_debug_view_meta)
     }
     __syncthreads();
     for (int t = (int)tid; t < T; t += (int)nthreads) {

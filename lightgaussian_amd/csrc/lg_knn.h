@@ -113,8 +113,12 @@ lg_knn_cells(int P, uint32_t cap, int level, const float* __restrict__ pts, cons
 // after the sort: cell ranges and a cell-ordered copy of the points {x, y, z, original index}
 __global__ void __launch_bounds__(256)
 lg_knn_ranges(int P, const float* __restrict__ pts, const uint64_t* __restrict__ pairs,
-              uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_end, float4* __restrict__ sorted)
+              uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_end, float4* __restrict__ sorted, const uint32_t* __restrict__ sort_err, uint32_t* __restrict__ box)
 {
+    // the cell sort of this level ran without a view's abort word: a onesweep look-back that exhausted its poll budget leaves
+    // LG_ABORT_SORT in the sort's own error word (ticket block, word 15), and pairs[] wrongly ordered.  Carry it to box[15], which
+    // the host reads once at the end of lg_knn3_mean_dist2 (the hipCUB sort this replaced had no silent failure mode)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (*sort_err & LG_ABORT_SORT)) box[15] = 1u;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const uint64_t kv = pairs[i];

@@ -6,9 +6,10 @@
 #include "lg_wave.h"
 
 // ------------------------------------------------------------------------------------------------
-// K1: preprocess.  One wave per workgroup, 64 consecutive Gaussians.  The SH rows of the wave (64 x 12M
-// bytes, contiguous in memory) are fetched with coalesced 16-byte loads into LDS -- skipping rows of
-// culled Gaussians -- instead of 48 strided dword loads per lane.
+// K1: preprocess.  One wave per workgroup, 64 consecutive Gaussians.  Default (DIRECT): every visible lane reads its own SH row with
+// dword-aligned 16-byte loads at the row stride (twelve pieces at degree 3; measured faster than staging).
+// LG_FLAG_K1_LDS (cross-check, option k1_lds) selects the round-1 form: the wave's rows (64 x 12M bytes, contiguous in memory) through
+// coalesced 16-byte loads into LDS, skipping rows of culled Gaussians.
 #define LG_PP 64
 #define LG_ID_BITS 29            // blend record, last word: Gaussian id | SH clamp flags << 29
 #define LG_ID_MASK ((1u << LG_ID_BITS) - 1u)
@@ -256,11 +257,11 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
 // ------------------------------------------------------------------------------------------------
 // K8 + K9 fused: per-Gaussian backward.  One wave per workgroup; SH rows in and dL/dSH rows out go
 // through LDS so that global traffic is coalesced 16-byte accesses.
-// 151 VGPRs -> 3 waves/SIMD.  Forcing 4 (amdgpu_waves_per_eu, 12 spilled registers) was measured: 0.37 -> 0.50 ms.
-// Reading the SH rows directly per lane as K1 does (only the visible rows, no input staging) was measured: 0.380 vs 0.380 ms.
+// Registers: JAC = false (the SH coefficients are re-read, sh[48] lives in registers) 155 VGPRs -> 3 waves/SIMD; forcing 4
+// (-DLG_K9_WAVES=4: 128 VGPRs, 76 B/lane of scratch) was measured in round 3: 0.384 -> 0.594 ms -- the spills cost more than the
+// fourth wave hides.  JAC = true (the default of every differentiated render since round 4: no coefficients, no input staging) 107 VGPRs
+// -> 4 waves/SIMD.  Reading the SH rows directly per lane as K1 does (JAC = false only) was measured: 0.380 vs 0.380 ms.
 template <bool RAW, bool JAC>
-// 155 VGPRs -> 3 waves/SIMD.  Forcing 4 (-DLG_K9_WAVES=4: 128 VGPRs, 76 B/lane of scratch) was measured in round 3:
-// 0.384 -> 0.594 ms -- the spills cost more than the fourth wave hides; 5 is not reachable (the compiler gives up at 157).
 #ifdef LG_K9_WAVES
 __global__ void __launch_bounds__(LG_PP) __attribute__((amdgpu_waves_per_eu(LG_K9_WAVES, 8)))
 #else

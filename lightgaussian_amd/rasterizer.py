@@ -46,7 +46,7 @@ _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": F
             "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
             "segment_length": 0, "long_tiles": "auto",
             # cross-check switches of the tests: never needed in production, never read from the environment
-            "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False}
+            "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False, "count_wide_band": False}
 _PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink")
 _LONG_TILES = ("serial", "auto", "parallel")
 _tls = threading.local()
@@ -90,6 +90,7 @@ def set_option(name, value):
               to the sink right behind K9 on the current stream, and returns None for the coefficient gradients: the caller
               rebuilds them for all ranks' views at once (parallel.RankOneSHExchange; the data-parallel step of lightgaussian_amd.dp);
     bwd_splat_parallel: the backward blend on the other parallel axis (round-5 prototype lg_blend_bwd_splat, DESIGN 22.1);
+    count_wide_band: tests only -- LG_FLAG_COUNT_WIDE_BAND (the parallel long-tile count walk sends many more pixels through its exact fix-up);
     sh_jacobian / narrow_key / sort_all_bits / k1_lds: cross-check switches for the tests (K9 re-reads the SH coefficients instead
               of K1's saved direction Jacobian; the sort key laid out as if 40 bits were available; every key bit through the
               global radix passes; K1's LDS-staged SH reads).  Options like everything else (r4 verdict: they used to be read
@@ -240,6 +241,8 @@ class _Call:
             flags |= _lib.FLAG_K1_LDS
         if opts["bwd_splat_parallel"]:
             flags |= _lib.FLAG_BWD_SPLAT_PARALLEL
+        if opts["count_wide_band"]:
+            flags |= _lib.FLAG_COUNT_WIDE_BAND
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                                  _ptr(self.bg), float(rs.scale_modifier), _ptr(self.vm), _ptr(self.pm),
                                  int(rs.sh_degree), _ptr(self.cp), int(bool(rs.prefiltered)), flags, int(opts["segment_length"]))

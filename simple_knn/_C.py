@@ -4,7 +4,7 @@ simple_knn.cu:185-221), consumed at scene/gaussian_model.py:152-156:
     dist2 = torch.clamp_min(distCUDA2(torch.from_numpy(np.asarray(pcd.points)).float().cuda()), 0.0000001)
 
 mean of the squared distances to the 3 nearest other points, exact.  Runs on the HIP library
-(lg_knn3_mean_dist2: multi-level uniform grid, one radix sort per level, no host sync); there is no CPU / PyTorch
+(lg_knn3_mean_dist2: multi-level uniform grid, one radix sort per level; one 4-byte read-back at the end says whether a sort gave up); there is no CPU / PyTorch
 fallback -- CPU tensors raise, like the CUDA extension does.
 """
 import ctypes as C

@@ -149,7 +149,10 @@ def test_three_iterations_through_the_distributed_runner_equal_the_in_process_lo
     if not flags:
         assert all(t is not None and t > 0.0 for t in rec["timings"])       # eager: loss.item() has drained the iteration, the pair is timed
     st = rec["stats"]
-    assert st["steps"] == STEPS and st["dense_steps"] == 0 and 0 < st["rows_exchanged"] <= STEPS * N     # the visible-rows path, through RCCL
+    # round 5: the SH groups through the rank-one exchange (all-gather of dRGB behind K9 + lg_sh_grad_from_rgb), the other four tensors
+    # through the dense bucketed all-reduce -- both through RCCL
+    assert st["steps"] == STEPS and st["rank1_sh_steps"] == STEPS and st["dense_steps"] == STEPS and st["rows_exchanged"] == 0
+    assert st["sh_bytes_on_wire"] == STEPS * (3 * N + 3) * 4
     got = torch.load(tmp_path / "params.pt")
     # the same loop in this process on the package's own functions
     import random

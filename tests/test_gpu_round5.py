@@ -197,3 +197,78 @@ def test_splat_parallel_backward_gives_the_gradients_of_the_pixel_parallel_one(c
             floor = gpu_common.rel_err(g32[name], g64[name])
             err = gpu_common.rel_err(np.asarray(gv).reshape(np.shape(g64[name])), g64[name])
             assert err <= max(1e-4, 3.0 * floor), f"{case} {name}: {err:.3e} (fp32 oracle floor {floor:.3e})"
+
+
+# ---- (d) parallel long-tile walk of the significance-only pass (lg_count_seg / _rewalk / _fixup) ---------------------------------------
+def _count_pass(g, cam, W, H, options):
+    """count_render as prune_list_sharded issues it (getters frozen, colours skipped) -> counts, scores, and the per-view meta words."""
+    import ctypes as C
+    from lightgaussian_amd import _lib, rasterizer
+    from lightgaussian_amd.rasterizer import GaussianRasterizationSettings
+    dev = torch.device(DEV)
+    with torch.no_grad():
+        t = dict(means3D=g.get_xyz.to(dev).contiguous(), opacities=g.get_opacity.to(dev).contiguous(), shs=g.get_features.to(dev).contiguous(),
+                 scales=g.get_scaling.to(dev).contiguous(), rotations=g.get_rotation.to(dev).contiguous())
+    camd = cam.to(dev)
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), 1.0, camd.world_view_transform,
+                                       camd.full_proj_transform, 3, camd.camera_center, False, False, True)
+    opts = rasterizer.resolve_options(dict(options, skip_color_in_count=True, sync_free=False))
+    call = rasterizer._Call(rs, t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None, exact=True, opts=opts)
+    lib = _lib.load()
+    _color, radii, cnt, score, _geom, binning, _img, R = rasterizer._native_forward(lib, call, rs, True)
+    meta = torch.zeros(16, dtype=torch.int32, device=dev)
+    _lib.check(lib.lg_debug_view_meta(C.byref(call.view), binning.data_ptr(), int(R), meta.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return cnt.cpu().numpy(), score.cpu().numpy(), meta.cpu().numpy().view(np.uint32), t
+
+
+COUNT_SCENES = [dict(N=5000, W=96, H=64, scale=0.12, opm=1.5, seed=17),        # opaque pile: pixels saturate inside the first segments
+                dict(N=9000, W=160, H=96, scale=0.06, opm=-0.5, seed=6),       # semi-opaque, deep: pixels saturate inside later segments, many never
+                dict(N=6000, W=130, H=70, scale=0.1, opm=0.5, seed=7)]
+
+
+@pytest.mark.parametrize("wide", [False, True], ids=["band", "wide_band"])
+@pytest.mark.parametrize("S", [64, 128])
+@pytest.mark.parametrize("sc", COUNT_SCENES, ids=lambda s: f"N{s['N']}_op{s['opm']}")
+def test_parallel_count_walk_gives_the_serial_counts_bit_for_bit(sc, S, wide):
+    """Significance-only pass, every multi-segment list through lg_count_seg / _rewalk / _fixup (long_tiles="parallel"): hit counts and
+    scores bit-identical to the serial walk and to the oracle.  wide_band: the comparison band 4096 x wider, so that the exact fix-up
+    resolves hundreds of pixels instead of (usually) none -- the counts must not move."""
+    g = _scene(N=sc["N"], seed=sc["seed"], scale=sc["scale"], opm=sc["opm"])
+    W, H = sc["W"], sc["H"]
+    cam = syn.orbit_camera(2, 7, W, H, radius=5.0)
+    base = {"segment_length": S}
+    c_ser, s_ser, m_ser, t = _count_pass(g, cam, W, H, dict(base, long_tiles="serial"))
+    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(base, long_tiles="parallel", count_wide_band=wide))
+    # (the serial pass launches no work-list workgroup: its meta words are whatever the allocator left there)
+    assert m_par[4] > 0 and m_par[2] == S and m_par[1] > 2 * S, m_par[:6]   # the parallel kernels really had items, of lists of several segments
+    assert np.array_equal(c_ser, c_par), f"{int((c_ser != c_par).sum())} counts differ, sum {int(c_ser.sum())} vs {int(c_par.sum())}, fix-ups {m_par[5]}"
+    assert np.array_equal(s_ser.view(np.uint32), s_par.view(np.uint32))
+    if wide:
+        assert m_par[5] > 0, "the wide band sent no pixel through the exact fix-up: the test does not exercise it"
+    kw = dict({k: v.cpu().numpy() for k, v in t.items()}, W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=np.zeros(3, np.float32),
+              viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), sh_degree=3)
+    ref = oracle.forward(count=True, **kw)
+    assert np.array_equal(c_par, ref.count) and np.array_equal(s_par.view(np.uint32), ref.score.view(np.uint32))
+    assert int(ref.count.sum()) > 10000
+
+
+def test_parallel_count_walk_on_the_heavy_tailed_scene():
+    """long_tiles="parallel" with the default segment length on a heavy-tailed scene (lists of thousands of entries): counts equal the
+    serial walk's; the default rule keeps the significance pass serial (measured faster with views in flight), and
+    count_render -- which returns an image -- always walks serially."""
+    from lightgaussian_amd.gaussian_renderer import count_render
+    g = syn.make_gaussians(400_000, seed=9)
+    syn.make_heavy_tailed(g, frac=0.08)
+    W, H = 960, 540
+    cam = syn.orbit_camera(0, 10, W, H)
+    c_ser, s_ser, _m, _ = _count_pass(g, cam, W, H, dict(long_tiles="serial"))
+    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(long_tiles="parallel"))
+    c_def, s_def, _m2, _ = _count_pass(g, cam, W, H, {})
+    assert m_par[4] > 0 and m_par[1] > 4 * 512, m_par[:6]
+    assert np.array_equal(c_ser, c_par) and np.array_equal(s_ser.view(np.uint32), s_par.view(np.uint32))
+    assert np.array_equal(c_ser, c_def)
+    dev = torch.device(DEV)
+    with torch.no_grad():
+        pkg = count_render(cam.to(dev), g.to(dev), syn.PipelineParams(), torch.zeros(3, device=dev))
+    assert np.array_equal(pkg["gaussians_count"].cpu().numpy(), c_ser)
