@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured-copy ceiling is 6290
-PROFILE_ROUND = "r04"  # profiles/<round>_profile_<mode>.json + <round>_<mode>_kernel_stats.csv: the rocprof evidence the roofline quotes
+PROFILE_ROUND = "r05"  # profiles/<round>_profile_<mode>.json + <round>_<mode>_kernel_stats.csv: the rocprof evidence the roofline quotes
 
 
 def parse():

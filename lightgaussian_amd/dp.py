@@ -44,7 +44,7 @@ import torch.distributed as dist
 from . import parallel
 
 _STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(), "steps": 0, "rows": 0, "dense_steps": 0,
-          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0}
+          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0, "mask_prev": None}
 # optimizer group name (scene/gaussian_model.py:204-211) -> attribute the fused rasterizer reports its gradient under
 _GROUP_OF = {"_xyz": "xyz", "_features_dc": "f_dc", "_features_rest": "f_rest", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
 
@@ -160,10 +160,15 @@ def _check_same_set(mask_bits, force=False):
     """Every rank must exchange the same set of parameters (the flat buffers are sized by it).  The set follows from the trainer's
     iteration logic -- e.g. train_densify_prune.py:194-197 swaps the opacity Parameter in reset_opacity() between backward() and
     step(), leaving that group without a gradient on EVERY rank -- so it is compared, not assumed: one 16-byte MAX all-reduce of
-    (mask, ~mask) in front of every exchange.  (Every step, not a sampled schedule: a rank whose set changed must not enter a
-    differently sized collective even once -- gloo aborts the process on a size mismatch, RCCL hangs.  ~20-40 us per step on RCCL,
-    unmeasured on hardware; LG_DP_TRUST=1 skips it.)"""
-    if os.environ.get("LG_DP_TRUST", "0") == "1":
+    (mask, ~mask).  When: the comparison reads its result on the host, i.e. it drains the device and costs the step its run-ahead,
+    so it is not made every step: on the first 8 steps, on every 64th, and on every step whose set differs from this rank's previous
+    one (ranks that change together -- the legitimate case -- all compare; a rank that changes ALONE enters a collective the others do
+    not, which fails in the collective itself: no schedule short of every step can turn that into a clean error).  LG_DP_CHECK_SET=1:
+    every step (tests); LG_DP_CHECK_SET=0: never."""
+    mode = os.environ.get("LG_DP_CHECK_SET", "")
+    n, prev = _STATE["steps"], _STATE.get("mask_prev")
+    _STATE["mask_prev"] = mask_bits
+    if mode == "0" or not (mode == "1" or n <= 8 or n % 64 == 0 or (prev is not None and prev != mask_bits)):
         return
     group = _STATE["group"]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")

@@ -355,6 +355,8 @@ class RankOneSHExchange:
                     torch.cuda.current_stream(xyz.device).wait_stream(self.comm)
                 else:
                     work.wait()
+                if gathered.is_cuda:
+                    gathered.record_stream(torch.cuda.current_stream(xyz.device))   # allocated on the side stream, consumed on this one
                 drgb = gathered[:, :3 * N].unflatten(1, (N, 3)) if gathered.dim() == 2 else gathered
                 cams = gathered[:, 3 * N:3 * N + 3].contiguous()
             else:

@@ -137,6 +137,7 @@ def _run(mode, views_per_step=1, reset_at=None):
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["LG_DP_CHECK"] = "0"
+    os.environ["LG_DP_CHECK_SET"] = "1"                # compare the parameter sets on every step (default: first steps, every 64th, on a change)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dp.install(Model, Scene)

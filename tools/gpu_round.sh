@@ -13,6 +13,8 @@ run --n-gaussians 1000000 --mode fwd --steps 100 --no-literal
 run --n-gaussians 3000000 --mode fwd --steps 100 --no-literal
 run --n-gaussians 3000000 --mode count --steps 100
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy
+run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1
+run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1 --long-tiles parallel --segment-length 2048
 run --n-gaussians 3000000 --mode count --steps 100 --scale 0.0045
 run --n-gaussians 3000000 --mode fwdbwd --steps 60 --no-fuse
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
@@ -35,9 +37,14 @@ timeout -s KILL 300 python tools/vq_bench.py 2>&1 | tail -4
 timeout -s KILL 420 python tools/gpu_fuzz.py 150 2>&1 | tail -2 | cut -c1-300
 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
 # the data-parallel step and the C4 leg of `bench.py --gpus N` through RCCL at world size 1 (the collectives are real, the wire is not)
-timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-literal --force-collectives 2>&1 | grep "^{" | tail -1 | python -c "
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-literal --force-collectives 2>/dev/null | grep "^{" | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('forced collectives:', d['value'], 'views/s', d.get('data_parallel'), d.get('c4_significance_pass'))" | cut -c1-1500
+for v in "--dense-allreduce" "--visible-allreduce" "--views-per-rank 4" "--dp-overlap"; do
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-literal --no-roofline --no-c4-leg --force-collectives $v 2>/dev/null | grep "^{" | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); dp = d.get('data_parallel') or {}; print('forced collectives $v:', d['value'], 'views/s', d['ms_per_step'], 'ms; exchange', dp.get('allreduce_ms'), 'ms, bytes on wire', dp.get('bytes_on_wire_per_step'))" | cut -c1-400
+done
 timeout -s KILL 300 python examples/significance_prune.py 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/finetune_step.py 2>&1 | tail -1 | cut -c1-300
 timeout -s KILL 300 python examples/finetune_step.py --fused-adam 2>&1 | tail -1 | cut -c1-300
