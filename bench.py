@@ -199,6 +199,23 @@ def dry_run(args, rank, world):
     dp_equal = all(torch.allclose(q.grad, d, rtol=1e-6, atol=1e-7) for q, d in zip(ps, dense))
     if world > 1:
         flag = torch.tensor([1 if dp_equal else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); dp_equal = bool(flag.item())
+    # the rank-one SH-gradient exchange (round 5) on synthetic per-rank dRGB: all-gather + local rebuild must equal the dense all-reduce of
+    # basis (x) dRGB (bit for bit at two ranks, to the summation order beyond)
+    xyz = g._xyz.detach()
+    cam_r = torch.tensor([3.0 * math.cos(0.9 * rank), 0.4 * rank - 0.5, 3.0 * math.sin(0.9 * rank)])
+    drgb = torch.randn((N, 3), generator=gen) * vis.view(-1, 1)
+    ex = parallel.RankOneSHExchange(force=False)
+    ex.add(drgb, cam_r, 3)
+    wire = ex.bytes_on_wire
+    g_dc, g_rest = ex.finish(xyz, 16)
+    d_dc, d_rest = parallel.sh_grad_from_rgb(xyz, cam_r.view(1, 3), drgb.unsqueeze(0), 3, 16)
+    dense_sh = torch.cat((d_dc, d_rest), dim=1)
+    if world > 1:
+        dist.all_reduce(dense_sh); dense_sh.div_(world)
+    r1 = torch.cat((g_dc, g_rest), dim=1)
+    r1_equal = torch.equal(r1, dense_sh) if world <= 2 else torch.allclose(r1, dense_sh, rtol=1e-6, atol=1e-7)
+    if world > 1:
+        flag = torch.tensor([1 if r1_equal else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); r1_equal = bool(flag.item())
     if rank == 0:
         c1, i1 = lg_prune.prune_list(g, cams, pipe, bg, count_fn=fake_count)
         m1 = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, i1, 0.1))
@@ -209,7 +226,8 @@ def dry_run(args, rank, world):
                           "counts_equal_1gpu": bool(torch.equal(c1, cnt)), "scores_bit_identical_1gpu": bool(torch.equal(i1, imp)),
                           "pruned": int(mask.sum().item()),
                           "data_parallel": {"allreduce_ms": round(dp_ms, 4), "rows_exchanged": rows, "rows_total": N, "equals_dense_allreduce": dp_equal,
-                                            "exchange": "rows seen by any rank's camera (allreduce_gradients_visible)"},
+                                            "exchange": "rows seen by any rank's camera (allreduce_gradients_visible)",
+                                            "rank_one_sh": {"equals_dense_allreduce": r1_equal, "bytes_on_wire": wire, "bytes_dense": int(2 * (world - 1) / world * N * 16 * 3 * 4)}},
                           "c4_pass": {"views": V, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "mask_sha256": digest,
                                       "mask_equals_1gpu": bool(torch.equal(m1, mask))}}), flush=True)
 

@@ -39,6 +39,10 @@ def test_self_launch_dry_run_prints_one_line_and_the_mask_equals_the_single_rank
     assert dpj["equals_dense_allreduce"] is True and dpj["rows_total"] == 4096
     assert (0 < dpj["rows_exchanged"] <= 4096) and (world == 1 or dpj["rows_exchanged"] > 2048)      # union of `world` half-visible sets
     assert c4["rccl_world_size"] == world and c4["mask_equals_1gpu"] is True and c4["mask_sha256"] == j["mask_sha256"]
+    # round 5: the rank-one SH-gradient exchange (all-gather of dRGB + local rebuild) against the dense all-reduce of basis (x) dRGB
+    r1 = dpj["rank_one_sh"]
+    assert r1["equals_dense_allreduce"] is True
+    assert r1["bytes_on_wire"] == (0 if world == 1 else (3 * 4096 + 3) * 4 * world) and (world == 1 or r1["bytes_on_wire"] < 0.2 * r1["bytes_dense"] * world)
 
 
 def test_mask_digest_is_the_same_for_every_world_size():
