@@ -971,7 +971,10 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
     const float G = __expf(power);                       // (power > 0: rejected by `ok`; see fwd_pair)
     const float op = b.y;
     const float alpha = guard_alpha(fminf(LG_ALPHA_MAX, op * G), op, power); // same decisions as the forward
-    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+    // the three compares as scalar lane masks, the valid set back to a predicate through inverse.ballot (round 5, as fwd_pair_m): the mask is
+    // also what the caller wants back -- rounds 1-4 returned ballot(am > 0), a fourth compare per pair step for the same set
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(live) & __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= LG_ALPHA_MIN);
+    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
     // am = alpha on valid lanes, 0 elsewhere: with am = 0 the colour recurrence below is the identity (S + 0 * d = S)
     // and dch = 0 (v_cndmask / v_cmp / v_min cost ~1.7x an fma on gfx950, tools/ubench/valu_rate2.hip).
     const float am = ok ? alpha : 0.0f;
@@ -990,6 +993,10 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
     S = am * d + S;
     const float dch = am * Tn;
     const float tdx = t * dx, tdy = t * dy;
+    // (round 5, measured and rejected: a wave-uniform `fresh` flag -- this is the entry's first evaluated sub-block -- under which this tail
+    //  ASSIGNS the nine sums, so that the caller need not zero them (nine v_mov per entry whenever sub-block 0 is not hit, 63 % of the
+    //  entries); only the tail existed twice, not the pair step as in round 3's attempt.  89 VGPRs instead of 83, 49 more vector
+    //  instructions of code: K7 0.5988 / 0.5967 / 0.5908 -> 0.5955 / 0.6095 / 0.6042 ms bracketed, three A/B pairs on one box.  Nothing.)
     p[0] += tdx;
     p[1] += tdy;
     p[2] += tdx * dx;
@@ -997,10 +1004,9 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
     p[4] += tdy * dy;
     p[5] += t;
     p[6] += dch * g0; p[7] += dch * g1; p[8] += dch * g2;
-    // the lanes that contributed.  `ok` is an AND of three lane masks, and a ballot of anything but a compare is materialised by
-    // hipcc as v_cndmask(0, 1) + v_cmp_ne -- two VALU instructions to copy a mask the scalar unit already holds (ISA of rounds
-    // 1-3).  am > 0 is the same set (alpha >= 1/255 on ok lanes, 0 elsewhere) and IS a compare: one instruction.
-    return __builtin_amdgcn_ballot_w64(am > 0.0f);
+    // the lanes that contributed: the scalar mask itself (rounds 1-3 balloted the bool `ok`, which hipcc materialises as v_cndmask(0, 1) +
+    // v_cmp_ne; round 4 balloted am > 0, one compare; now none)
+    return okm;
 }
 
 #ifndef LG_K7_WAVES

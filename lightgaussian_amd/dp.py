@@ -44,7 +44,7 @@ import torch.distributed as dist
 from . import parallel
 
 _STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(), "steps": 0, "rows": 0, "dense_steps": 0,
-          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0, "mask_prev": None}
+          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0, "mask_prev": None, "overlap": None}
 # optimizer group name (scene/gaussian_model.py:204-211) -> attribute the fused rasterizer reports its gradient under
 _GROUP_OF = {"_xyz": "xyz", "_features_dc": "f_dc", "_features_rest": "f_rest", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
 
@@ -231,6 +231,24 @@ def exchange_gradients(optimizer, check=None, force=False):
         _STATE["wire_bytes"] += sink.bytes_on_wire
         _STATE["sh_wire_bytes"] += sink.bytes_on_wire
         info.update(mode="rank1_sh+dense", sh_bytes_on_wire=sink.bytes_on_wire)
+    ov = _STATE.get("overlap")
+    if ov is not None and ov.grads is not None:
+        # LG_DP_OVERLAP=1 / run.py --dp-overlap: the step's ONE rasterizer backward ran its per-Gaussian stage in ranges, and each range of the
+        # (non-SH) gradient tensors was all-reduced on a side stream while K9 computed the next one (parallel.OverlappedGradAllReduce over
+        # lg_backward_chunked).  The reduced tensors replace what autograd put into the leaves; whatever the hook did not see -- the literal
+        # getter pattern reports gradients of the ACTIVATED tensors, which are not parameters -- goes through the dense all-reduce below.
+        reduced = ov.finish(None)
+        ov.grads = None
+        done = []
+        if all(n in _GROUP_OF for n in reduced):
+            for n, g in reduced.items():
+                q = by_name.get(_GROUP_OF[n])
+                if q is not None and q.grad is not None and q.grad.numel() == g.numel():
+                    q.grad = g.view_as(q)
+                    done.append(q)
+        have = [q for q in have if not any(q is d for d in done)]
+        info["overlapped"] = len(done)
+        _STATE["overlap_steps"] = _STATE.get("overlap_steps", 0) + (1 if done else 0)
     if not have:
         return info
     N = have[0].shape[0]
@@ -294,10 +312,17 @@ def shard_cameras(cams, rank, world):
     return mine if mine else list(cams)
 
 
-def install(gaussian_model_cls=None, scene_cls=None, group=None):
+def install(gaussian_model_cls=None, scene_cls=None, group=None, overlap=None):
     """Hang the data-parallel glue on the reference's classes (see the module docstring).  Safe to call at world size 1 (every hook
-    degenerates to the original behaviour).  uninstall() restores the classes."""
+    degenerates to the original behaviour).  uninstall() restores the classes.
+    overlap (default: env LG_DP_OVERLAP=1): all-reduce the non-SH gradients in ranges behind K9 instead of after backward() returns
+    (one rasterizer backward per optimizer step, as all three reference trainers have it; a second one before step() raises)."""
     _STATE["group"] = group
+    if overlap is None:
+        overlap = os.environ.get("LG_DP_OVERLAP", "0") == "1"
+    if overlap and (active() or _forced()) and _STATE.get("overlap") is None:
+        _STATE["overlap"] = parallel.OverlappedGradAllReduce(group, chunks=4)
+        _STATE["overlap"].__enter__()
     if scene_cls is not None and hasattr(scene_cls, "getTrainCameras") and not hasattr(scene_cls, "_lg_all_train_cameras"):
         orig_get = scene_cls.getTrainCameras
 
@@ -370,12 +395,15 @@ def uninstall():
                 pass
     _STATE["visible"].clear()
     _STATE["sinks"].clear()
+    if _STATE.get("overlap") is not None:
+        _STATE["overlap"].__exit__(None, None, None)
+        _STATE["overlap"] = None
     _STATE["group"] = None
 
 
 def stats():
     """Counters of the exchanges so far: steps, rows exchanged (visible mode), steps that fell back to the dense all-reduce."""
     return {"steps": _STATE["steps"], "rows_exchanged": _STATE["rows"], "dense_steps": _STATE["dense_steps"],
-            "rank1_sh_steps": _STATE["sh_steps"], "bytes_on_wire": _STATE["wire_bytes"], "sh_bytes_on_wire": _STATE["sh_wire_bytes"]}
+            "rank1_sh_steps": _STATE["sh_steps"], "overlapped_steps": _STATE.get("overlap_steps", 0), "bytes_on_wire": _STATE["wire_bytes"], "sh_bytes_on_wire": _STATE["sh_wire_bytes"]}
     # (bytes_on_wire: what a ring moves through this rank -- 2 (w - 1) / w of the payload for an all-reduce, payload x w for the
     #  all-gather of dRGB (own block sent once, w - 1 blocks received); an estimate from the tensor sizes, not a counter)

@@ -351,6 +351,8 @@ def main(argv=None):
             no_patch = True
         elif flag == "--verbose":
             verbose = True
+        elif flag == "--dp-overlap":              # with --distributed: non-SH gradients all-reduced in ranges behind K9 (dp.install(overlap=True))
+            os.environ["LG_DP_OVERLAP"] = "1"
         elif flag == "--fused-adam":
             adam = True
         elif flag == "--lazy-loss":
@@ -360,7 +362,7 @@ def main(argv=None):
         elif flag.startswith("--backend="):       # gloo: CPU tests of the launcher with a stand-in trainer (the rasterizer has no CPU path)
             backend = flag.split("=", 1)[1]
         else:
-            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --no-patch --verbose --fused-adam --lazy-loss --no-iter-timing, then the script and ITS arguments)")
+            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --dp-overlap --no-patch --verbose --fused-adam --lazy-loss --no-iter-timing, then the script and ITS arguments)")
     if not argv:
         raise SystemExit(__doc__)
     script = os.path.abspath(argv[0])

@@ -94,13 +94,38 @@ class _SHColor(torch.autograd.Function):
         return None, full[:, :1], full[:, 1:], None, None
 
 
+class _Geom(torch.autograd.Function):
+    """the geometric parameters with the rasterizer's OTHER contract: when a gradient-chunk hook is installed (rasterizer.set_grad_chunk_hook,
+    i.e. parallel.OverlappedGradAllReduce), the backward reports its gradient tensors range by range, as lg_backward_chunked does."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, w):
+        ctx.save_for_backward(scaling, rotation, w)
+        return (xyz * w).sum(1) + (torch.exp(scaling) * w).sum(1) + (rotation * w).pow(2).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from lightgaussian_amd import rasterizer
+        scaling, rotation, w = ctx.saved_tensors
+        g = g.unsqueeze(1)
+        g_xyz = (g * w).expand(-1, 3).contiguous()
+        g_sc = g * torch.exp(scaling) * w
+        g_rot = g * 2.0 * rotation * w * w
+        hook = rasterizer._GRAD_CHUNKS["hook"]
+        if hook is not None:
+            grads = {"_xyz": g_xyz, "_scaling": g_sc, "_rotation": g_rot}
+            for first in range(0, N, 80):
+                hook(first, min(80, N - first), grads)
+        return g_xyz, g_sc, g_rot, None
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, *, options=None):
     cam = int(viewpoint_camera)
     campos = _campos(cam)
     vis = (pc._xyz.detach() @ campos) > -0.3
     w = vis.float().view(-1, 1)
     rgb = _SHColor.apply(pc._xyz, pc._features_dc, pc._features_rest, campos, (options or {}).get("sh_grad_sink"))
-    feat = (rgb * w).sum(1) * torch.sigmoid(pc._opacity.view(N)) + (pc._xyz * w).sum(1) + (torch.exp(pc._scaling) * w).sum(1) + (pc._rotation * w).pow(2).sum(1)
+    feat = (rgb * w).sum(1) * torch.sigmoid(pc._opacity.view(N)) + _Geom.apply(pc._xyz, pc._scaling, pc._rotation, w)
     image = torch.sin(feat * (1.0 + 0.1 * cam)).view(1, 1, N)
     points = torch.zeros(N, 3, requires_grad=True)
     return {"render": image + 0.0 * points.sum(), "viewspace_points": points, "visibility_filter": vis, "radii": vis.int() * (3 + cam)}
@@ -123,8 +148,10 @@ def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None
             model.optimizer.zero_grad(set_to_none=True)
 
 
-def _run(mode, views_per_step=1, reset_at=None):
+def _run(mode, views_per_step=1, reset_at=None, overlap=False):
     os.environ["LG_DP_SH"] = mode
+    dp.uninstall()
+    dp.install(Model, Scene, overlap=overlap)
     random.seed(0); torch.manual_seed(0)
     model, scene = Model(), Scene()
     model.training_setup(None)
@@ -152,6 +179,13 @@ def _worker(rank, world, port, out_dir):
                 same = torch.equal(p, q) if tag != "two" else torch.allclose(p, q, rtol=1e-6, atol=1e-7)
                 assert same, f"{tag}: {n} differs between the rank-one and the dense exchange on rank {rank}"
             res[tag] = [p.detach().numpy() for p in a._params()]
+            if tag != "two":
+                # the non-SH gradients all-reduced range by range from inside the backward (one backward per step): the same bits, and the
+                # opacity group -- which the hook never sees here -- still goes through the dense all-reduce
+                c, sc = _run("rank1", overlap=True, **kw)
+                assert sc["overlapped_steps"] == 3 and sa["overlapped_steps"] == 0
+                for n, p, q in zip(NAMES, a._params(), c._params()):
+                    assert torch.equal(p, q), f"{tag}: {n} differs with the overlapped all-reduce on rank {rank}"
             # wire bytes of the SH part: (3 N + 3) floats per view sent once, received from the other rank
             if tag != "reset":
                 k = kw.get("views_per_step", 1)
