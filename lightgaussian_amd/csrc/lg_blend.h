@@ -276,6 +276,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             for (uint32_t j = 0; j < nhit; j++) pair(j);
             if (COUNT) {
                 // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
+                // (round 5 ablation, profiles/r05_call_count_band.log: without these atomics the kernel takes 287 us instead of 328)
                 if (lane < nhit && mycnt > 0) {
                     const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
                     atomicAdd(&count[id], mycnt);
@@ -658,6 +659,43 @@ __device__ __forceinline__ void lg_count_scan_tile(int W, int H, int gx, int S, 
     cl[0] = 0u;
 }
 
+// The exact resolution of ONE pixel (passes 4 of the parallel walk and of the banded walk below): the pixel's walk from the start of the
+// tile's list with the ENTRIES on the lanes -- canonical alpha of 64 entries at a time, then the sequential product over the contributing
+// ones in list order (T is wave-uniform), the very operation sequence of the serial canonical walk -- up to the stop; entries from list
+// position jstar on are counted.  No block culling: it only ever drops entries that contribute to no pixel of the block.
+__device__ __forceinline__ void lg_count_exact_pixel(const uint2 range, const uint64_t* __restrict__ entries, uint32_t gid_mask,
+                                                     const float4* __restrict__ rec, float pxf, float pyf, uint32_t jstar, int32_t* __restrict__ count,
+                                                     uint32_t lane)
+{
+    const uint32_t n = range.y - range.x;
+    float T = 1.0f;
+    bool stopped = false;
+    for (uint32_t base = 0; base < n && !stopped; base += LG_Q) {
+        const uint32_t e = base + lane;
+        float alpha = 0.0f;
+        bool ok = false;
+        uint32_t id = 0;
+        if (e < n) {
+            id = (uint32_t)entries[range.x + e] & gid_mask;
+            const float4 a = rec[LG_REC_F4 * (size_t)id], b = rec[LG_REC_F4 * (size_t)id + 1];
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
+            alpha = fminf(LG_ALPHA_MAX, b.y * lg_exp(fminf(power, 0.0f)));
+            ok = (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
+        }
+        uint64_t cntm = 0ull;
+        for (uint64_t okm = __builtin_amdgcn_ballot_w64(ok); okm != 0ull; okm &= okm - 1ull) {
+            const int bit = (int)__builtin_ctzll(okm);
+            const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), bit));
+            const float test_T = T * (1.0f - al);
+            if (test_T < LG_T_MIN) { stopped = true; break; }
+            T = test_T;
+            if (base + (uint32_t)bit + 1u >= jstar) cntm |= 1ull << bit;
+        }
+        if ((cntm >> lane) & 1ull) atomicAdd(&count[id], 1);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 lg_count_seg(int W, int H, int gx, int S, const uint2* __restrict__ par_work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, float4* __restrict__ ckpt,
@@ -790,37 +828,19 @@ lg_count_fixup(int W, int H, int gx, int S, const uint2* __restrict__ par_work, 
             const uint32_t jstar = (uint32_t)__builtin_amdgcn_readlane((int)myflag, src);
             if (lane == 0u) atomicAdd(&meta[5], 1u);
             const float pxf = (float)__builtin_amdgcn_readlane(pxi, src), pyf = (float)__builtin_amdgcn_readlane(pyi, src);
-            // the frozen pixel's walk from the start of the list, entries on the lanes; T is wave-uniform
-            float T = 1.0f;
-            bool stopped = false;
-            for (uint32_t base = 0; base < n && !stopped; base += LG_Q) {
-                const uint32_t e = base + lane;
-                float alpha = 0.0f;
-                bool ok = false;
-                uint32_t id = 0;
-                if (e < n) {
-                    id = (uint32_t)entries[range.x + e] & gid_mask;
-                    const float4 a = rec[LG_REC_F4 * (size_t)id], b = rec[LG_REC_F4 * (size_t)id + 1];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
-                    alpha = fminf(LG_ALPHA_MAX, b.y * lg_exp(fminf(power, 0.0f)));
-                    ok = (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
-                }
-                uint64_t cntm = 0ull;
-                for (uint64_t okm = __builtin_amdgcn_ballot_w64(ok); okm != 0ull; okm &= okm - 1ull) {
-                    const int bit = (int)__builtin_ctzll(okm);
-                    const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), bit));
-                    const float test_T = T * (1.0f - al);
-                    if (test_T < LG_T_MIN) { stopped = true; break; }
-                    T = test_T;
-                    if (base + (uint32_t)bit + 1u >= jstar) cntm |= 1ull << bit;
-                }
-                if ((cntm >> lane) & 1ull) atomicAdd(&count[id], 1);
-            }
+            lg_count_exact_pixel(range, entries, gid_mask, rec, pxf, pyf, jstar, count, lane);
         }
     }
 }
 
+// (Round 5, measured and rejected -- profiles/r05_call_count_band.log: the serial walk of the significance-only pass with the HARDWARE exp, the
+//  stop decided through the same kind of error band as above (a factor 1 - alpha differs from its canonical twin by at most 7.6e-7 alpha /
+//  (1 - alpha): v_exp_f32 1 ulp, its argument rounded at |x log2 e| <= 8, lg_exp within 7.8e-8 of exp) and the undecided pixels resolved by
+//  lg_count_exact_pixel from a per-pixel flag plane.  Counts bit-identical to the canonical walk and the oracle on 12 scene families + 40
+//  random scenes, 32 vector instructions per pair step instead of ~45 -- and no faster: lg_blend_count_band 342 us against 333 us for
+//  lg_blend_fwd<COUNT, EXACT> on the uniform scene (the count kernel is not bound by the exp polynomial: without its atomics it takes 287 us,
+//  the colour forward with v_exp 260), 941 + 858 us against 846 on the heavy-tailed scene, where 451 pixels per view had to be resolved one
+//  after the other by the waves that own them.  Removed.)
 // per-view score from the exact integer count (ONE / OPACITY weights)
 __global__ void __launch_bounds__(256)
 lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score)

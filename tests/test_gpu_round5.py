@@ -272,3 +272,4 @@ def test_parallel_count_walk_on_the_heavy_tailed_scene():
     with torch.no_grad():
         pkg = count_render(cam.to(dev), g.to(dev), syn.PipelineParams(), torch.zeros(3, device=dev))
     assert np.array_equal(pkg["gaussians_count"].cpu().numpy(), c_ser)
+
