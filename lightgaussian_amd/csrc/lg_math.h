@@ -58,23 +58,6 @@ LG_HD float lg_exp(float x)
 // c atomicAdd(float*, w) calls produce (all addends equal, so order independent).  O(#binades)
 // instead of O(c): inside one binade every step adds the same multiple of the ulp, so the run
 // of identical steps is applied as one exact integer multiply.  SURVEY.md section 8a-note.
-// floor(a / b) for a < 2^24, 0 < b < 2^24 (both exact as floats): reciprocal estimate, then exact correction -- the estimate is within a
-// few units whatever the reciprocal's last bits are (v_rcp_f32 on the device, a division on the host), so the result does not depend on
-// them.  Replaces a 32-bit integer division (~35 instructions on gfx950) in the per-binade step of lg_seqsum32 (round 5: lg_score_kernel
-// 41 -> ~28 us per view at C3).
-LG_HD uint32_t lg_udiv24(uint32_t a, uint32_t b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float rb = __builtin_amdgcn_rcpf((float)b);
-#else
-    const float rb = 1.0f / (float)b;
-#endif
-    uint32_t q = (uint32_t)((float)a * rb);
-    while (q * b > a) q--;                       // (q b <= a + 4 b < 2^27: no overflow)
-    while ((q + 1u) * b <= a) q++;
-    return q;
-}
-
 LG_HD float lg_seqsum32(float w, uint32_t c)
 {
     float s = 0.0f;
@@ -100,7 +83,9 @@ LG_HD float lg_seqsum32(float w, uint32_t c)
         uint32_t inc = ud - ub;                                    // steady increment in ulps
         if (inc == 0) return s;
         uint32_t top = (e << 23) | 0x7FFFFFu;                      // largest value of this binade
-        uint32_t room = lg_udiv24(top - ud, inc);                  // steps that stay inside it (both < 2^23)
+        // (round 5, measured: a reciprocal estimate + exact correction instead of this integer division changes nothing -- lg_score_kernel
+        //  41.3 -> 44.5 us at C3, box noise: the kernel's time is the divergent walk over the binades, not the division)
+        uint32_t room = (top - ud) / inc;                          // steps that stay inside it
         uint32_t k = room < c ? room : c;
         s = lg_bits2f(ud + k * inc);
         c -= k;

@@ -13,7 +13,6 @@ extern "C" {
 
 float h_exp(float x) { return lg_exp(x); }
 float h_seqsum32(float w, uint32_t c) { return lg_seqsum32(w, c); }
-uint32_t h_udiv24(uint32_t a, uint32_t b) { return lg_udiv24(a, b); }
 
 struct HSplat { LgSplat s; float op, rgb[3], cov[6]; uint32_t clamp; int vis; };
 

@@ -40,21 +40,6 @@ def test_seqsum32_equals_sequential_adds():
             assert _bits(a) == _bits(b), (w, c, a, b)
 
 
-def test_udiv24_is_the_exact_quotient():
-    """lg_udiv24 (reciprocal estimate + exact correction, the per-binade step of lg_seqsum32 since round 5) against Python's //, on the
-    edges and on random operands below 2^24 (the GPU evaluates the estimate with v_rcp_f32: the correction makes the result independent of
-    the reciprocal's last bits -- the device path is pinned by every bit-identical score test)."""
-    lib = common.harness()
-    rs = np.random.RandomState(5)
-    M = (1 << 24) - 1
-    cases = [(0, 1), (1, 1), (M, 1), (M, M), (M - 1, M), (M, 2), (M, 3), (8388607, 1), (8388607, 8388607), (8388606, 8388607), (12345, 1), (7, 8)]
-    cases += [(int(a), int(b)) for a, b in zip(rs.randint(0, M + 1, 20000), rs.randint(1, M + 1, 20000))]
-    cases += [(int(a), int(b)) for a, b in zip(rs.randint(0, M + 1, 20000), rs.randint(1, 64, 20000))]            # small divisors: large quotients
-    cases += [(int(q * b + r) if q * b + r <= M else M, int(b)) for q, b, r in zip(rs.randint(0, 4096, 20000), rs.randint(1, 4096, 20000), rs.randint(-2, 3, 20000)) if q * b + r >= 0]
-    for a, b in cases:
-        assert lib.h_udiv24(a, b) == a // b, (a, b)
-
-
 def test_seqsum32_random_weights_and_counts():
     lib = common.harness()
     rs = np.random.RandomState(9)
