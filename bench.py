@@ -259,7 +259,11 @@ def main():
         if "RANK" not in os.environ and args.gpus > 1:
             self_launch(args)            # bare `python bench.py --gpus N`: become N ranks (does not return)
         _error_record(args, f"WORLD_SIZE={world} does not match --gpus {args.gpus}", 2)
-    if args.backend == "gloo" and not args.dry_run:
+    # --backend gloo outside --dry-run: TEST MODE, LG_BENCH_SHARE_GPU=1 only -- every rank renders on cuda:0 and the collectives run
+    # over gloo on device tensors: the one way to run the REAL multi-rank step (kernels, rank-one SH exchange, dense all-reduce, the
+    # per-rank camera schedule) at world size > 1 on a 1-GPU box (tests/test_gpu_round5.py).  Not a measurement: its line says so.
+    share_gpu = args.backend == "gloo" and not args.dry_run and os.environ.get("LG_BENCH_SHARE_GPU") == "1"
+    if args.backend == "gloo" and not args.dry_run and not share_gpu:
         _error_record(args, "--backend gloo is for --dry-run only: the rasterizer has no CPU path", 2)
     if args.dry_run:
         if world > 1:
@@ -272,13 +276,18 @@ def main():
         return
     if not torch.cuda.is_available():
         _error_record(args, "bench.py needs an MI355X: the rasterizer has no CPU path", 3)
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         _error_record(args, f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)", 3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or (args.force_collectives and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from lightgaussian_amd import _lib, synthetic as syn
     from lightgaussian_amd import rasterizer
@@ -638,6 +647,19 @@ def main():
             del c1, i1, m1
         del cnt, imp, mask_all
         extra["c4_significance_pass"] = c4
+    if dp_step and args.mode == "fwdbwd" and dist.is_initialized():
+        # every rank holds the same averaged gradients after a step: compare a digest of the last step's (all six tensors) across the ranks
+        import hashlib
+        step(0)                    # (one more step on a FIXED camera: the digest is a function of the inputs, not of how many steps the ~1 s loop ran)
+        h, per = hashlib.sha256(), []
+        for p in params:
+            b = (p.grad.detach() + 0.0).contiguous().cpu().numpy().tobytes()          # (+ 0.0: -0.0 and +0.0 hash alike -- equal values, equal digest)
+            h.update(b); per.append(hashlib.sha256(b).hexdigest()[:16])
+        digs = [None] * dist.get_world_size()
+        dist.all_gather_object(digs, h.hexdigest())
+        extra["gradients_identical_on_all_ranks"] = len(set(digs)) == 1
+        extra["gradient_sha256"] = digs[0]
+        extra["gradient_sha256_per_tensor"] = dict(zip(("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"), per))
     if comm_events:
         # data-parallel step: how much of it is the gradient exchange (hipEvents around the collectives of the last
         # timed steps on this rank's stream; no multi-GPU timing existed before round 3's first driver run)
@@ -697,6 +719,8 @@ def main():
                        "parallelism": (f"dp{world}: {KV} camera(s) per rank per step, gradients averaged over RCCL before the next step" if dp_step else
                                        f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},
         }
+        if share_gpu:
+            result["test_mode"] = "LG_BENCH_SHARE_GPU=1: all ranks on cuda:0, collectives over gloo -- a functional check of the multi-rank step, not a measurement"
         result.update(extra)
 
     # ---- roofline leg: per-kernel hipEvent timings of the same step (separate, untimed pass) ----

@@ -327,7 +327,10 @@ class RankOneSHExchange:
                 # one message per view: the centre rides behind the colours in the same buffer
                 payload = torch.cat((drgb.reshape(-1), campos))
                 gathered = torch.empty((self.world, 3 * N + 3), dtype=drgb.dtype, device=drgb.device)
-                work = dist.all_gather_into_tensor(gathered, payload, group=self.group, async_op=True)
+                if dist.get_backend(self.group) == "nccl":
+                    work = dist.all_gather_into_tensor(gathered, payload, group=self.group, async_op=True)
+                else:           # (gloo on device tensors: the shared-GPU test mode of bench.py)
+                    work = dist.all_gather(list(gathered.unbind(0)), payload, group=self.group, async_op=True)
             drgb.record_stream(self.comm)
         else:
             payload = torch.cat((drgb.reshape(-1), campos))

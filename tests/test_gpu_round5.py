@@ -273,3 +273,41 @@ def test_parallel_count_walk_on_the_heavy_tailed_scene():
         pkg = count_render(cam.to(dev), g.to(dev), syn.PipelineParams(), torch.zeros(3, device=dev))
     assert np.array_equal(pkg["gaussians_count"].cpu().numpy(), c_ser)
 
+
+
+# ---- (e) the data-parallel step of bench.py at world size 2 on ONE GPU (collectives over gloo on device tensors) -----------------------
+def _bench_two_ranks(tmp_path, *extra):
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LG_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--n-gaussians", "150000", "--width", "480",
+           "--height", "272", "--views", "8", "--scale", "0.02", "--no-cpu-baseline", "--no-roofline", "--no-literal", "--no-c4-leg", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=common.ROOT, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_data_parallel_step_with_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` for real -- two processes, the real kernels, the per-rank camera shard, the rank-one SH exchange behind K9, the
+    dense all-reduce of the other four tensors -- on the one GPU of this box (LG_BENCH_SHARE_GPU=1: both ranks on cuda:0, collectives over
+    gloo).  Every rank must end a step with the same gradients; the rank-one exchange must give the gradients of the dense exchange BIT
+    FOR BIT (two ranks: (t0 + t1) / 2 either way); a camera batch per rank and the overlapped all-reduce must run."""
+    r1 = _bench_two_ranks(tmp_path)
+    dn = _bench_two_ranks(tmp_path, "--dense-allreduce")
+    assert r1["n_gpus"] == 2 and "test_mode" in r1 and r1["data_parallel"]["views_per_rank_per_step"] == 1
+    assert r1["gradients_identical_on_all_ranks"] is True and dn["gradients_identical_on_all_ranks"] is True
+    assert r1["gradient_sha256"] == dn["gradient_sha256"], "rank-one SH exchange and dense all-reduce left different gradients"
+    assert 0 < r1["data_parallel"]["bytes_on_wire_per_step"] < 0.5 * dn["data_parallel"]["bytes_on_wire_per_step"]
+    ov = _bench_two_ranks(tmp_path, "--dp-overlap")
+    assert ov["gradients_identical_on_all_ranks"] is True and ov["gradient_sha256"] == r1["gradient_sha256"], (ov["gradient_sha256_per_tensor"], r1["gradient_sha256_per_tensor"])
+    kv = _bench_two_ranks(tmp_path, "--views-per-rank", "2")
+    assert kv["gradients_identical_on_all_ranks"] is True and kv["data_parallel"]["views_per_rank_per_step"] == 2
+    vis = _bench_two_ranks(tmp_path, "--visible-allreduce")
+    assert vis["gradients_identical_on_all_ranks"] is True and vis["gradient_sha256"] == dn["gradient_sha256"]
