@@ -113,7 +113,13 @@ for iteration in range(1, {STEPS} + 1):                     # prune_finetune.py:
 from lightgaussian_amd import dp
 import torch.distributed as dist
 out = os.environ["LG_TEST_OUT"]
-torch.save({{n: getattr(gaussians, n).detach().cpu() for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}}, os.path.join(out, "params.pt"))
+_rk = os.environ.get("RANK", "0")
+_state = {{n: getattr(gaussians, n).detach().cpu() for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}}
+torch.save(_state, os.path.join(out, f"params_r{{_rk}}.pt"))
+if _rk != "0":
+    json.dump(dict(picked=picked, stats=dp.stats()), open(os.path.join(out, f"rec_r{{_rk}}.json"), "w"))
+    sys.exit(0)
+torch.save(_state, os.path.join(out, "params.pt"))
 json.dump(dict(picked=picked, stats=dp.stats(), world=dist.get_world_size() if dist.is_initialized() else 0, backend=dist.get_backend() if dist.is_initialized() else None,
                render=render.__module__, wrapped=hasattr(render, "__wrapped__"), argv=sys.argv[1:], ncams=len(scene.getTrainCameras()),
                ema=ema_loss_for_log, timings=[t if t == t else None for t in timings], kinds=sorted(kinds)), open(os.path.join(out, "rec.json"), "w"))
@@ -180,3 +186,48 @@ def test_three_iterations_through_the_distributed_runner_equal_the_in_process_lo
             opt.step(); opt.zero_grad(set_to_none=True)
     for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
         assert torch.equal(got[n], getattr(m, n).detach().cpu()), n
+
+
+def _write_checkout(tmp_path):
+    root = tmp_path / "LightGaussian"
+    for d in ("gaussian_renderer", "utils", "scene"):
+        (root / d).mkdir(parents=True)
+    (root / "gaussian_renderer" / "__init__.py").write_text(_RENDER)
+    (root / "utils" / "__init__.py").write_text("")
+    (root / "utils" / "loss_utils.py").write_text(_LOSS)
+    (root / "scene" / "gaussian_model.py").write_text(_MODEL)
+    (root / "scene" / "__init__.py").write_text(_SCENE)
+    (root / "prune.py").write_text("def prune_list(gaussians, scene, pipe, background):\n    raise NotImplementedError\ndef calculate_v_imp_score(gaussians, imp_list, v_pow):\n    raise NotImplementedError\n")
+    (root / "trainer.py").write_text(_TRAINER)
+    return root
+
+
+def test_two_ranks_of_the_distributed_runner_on_one_gpu_train_one_model(tmp_path):
+    """`run.py --distributed` at world size 2 with the real kernels: both ranks on the one GPU of this box, collectives over gloo on device
+    tensors (--backend=gloo).  The reference-shaped trainer (camera shard per rank, loss line, loss.item(), Adam) runs three iterations:
+    both ranks end with the same parameters, bit for bit, in the round-5 exchange (rank-one SH gradients + dense rest) and in the dense
+    one (LG_DP_SH=dense), and the two exchanges leave the same parameters."""
+    res = {}
+    for mode in ("rank1", "dense"):
+        out = tmp_path / mode
+        out.mkdir()
+        root = _write_checkout(out)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, LG_TEST_OUT=str(out), LG_DP_SH=mode, LG_DP_CHECK_SET="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            "-m", "lightgaussian_amd.run", "--distributed", "--backend=gloo", str(root / "trainer.py"), "-m", "out"],
+                           capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+        assert r.returncode == 0, "\n".join(l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "rank" in l)[-3000:]
+        p0, p1 = torch.load(out / "params_r0.pt"), torch.load(out / "params_r1.pt")
+        for n in p0:
+            assert torch.equal(p0[n], p1[n]), f"{mode}: {n} differs between the ranks"
+        rec0, rec1 = json.load(open(out / "rec.json")), json.load(open(out / "rec_r1.json"))
+        assert rec0["world"] == 2 and rec0["backend"] == "gloo" and not (set(rec0["picked"]) & set(rec1["picked"]))     # disjoint camera shards
+        assert rec0["stats"]["rank1_sh_steps"] == (STEPS if mode == "rank1" else 0)
+        res[mode] = p0
+    for n in res["rank1"]:
+        assert torch.equal(res["rank1"][n], res["dense"][n]), f"{n}: the rank-one exchange and the dense exchange trained different models"
+    g = syn.make_gaussians(N, seed=5, log_scale_mean=math.log(0.03))
+    assert not torch.equal(res["rank1"]["_features_rest"], g._features_rest)        # and they did train
