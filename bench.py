@@ -717,6 +717,7 @@ def main():
                                 "l1_dssim_lazy": "0.8*L1 + 0.2*(1-SSIM), fused HIP kernels, the reference's two calls + formula on lazy scalars (loss_utils.set_lazy)",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
                        "parallelism": (f"dp{world}: {KV} camera(s) per rank per step, gradients averaged over RCCL before the next step" if dp_step else
+                                       f"camera-shard x{world}: counts all-reduced, scores exchanged in view order (prune_list_sharded)" if (args.mode == "count" and world > 1) else
                                        f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},
         }
         if share_gpu:

@@ -311,3 +311,33 @@ def test_bench_data_parallel_step_with_two_ranks_on_one_gpu(tmp_path):
     assert kv["gradients_identical_on_all_ranks"] is True and kv["data_parallel"]["views_per_rank_per_step"] == 2
     vis = _bench_two_ranks(tmp_path, "--visible-allreduce")
     assert vis["gradients_identical_on_all_ranks"] is True and vis["gradient_sha256"] == dn["gradient_sha256"]
+
+
+def test_bench_c4_pass_with_two_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] in miniature, for real at world size 2 (two processes on this box's one GPU, collectives over gloo): the sharded
+    significance pass of `bench.py --mode count` (int32 count all-reduce, round-wise ordered all_to_all of the scores, all_gather) and the
+    C4 leg of the default line: counts, ordered scores and the prune mask equal to the single-rank pass recomputed on rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    def run(*extra):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, LG_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-gaussians", "150000", "--width", "480", "--height", "272",
+               "--scale", "0.02", "--no-cpu-baseline", "--no-roofline", "--no-literal", *extra]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=common.ROOT, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+        return json.loads(lines[0])
+    c = run("--mode", "count", "--steps", "7", "--warmup", "2", "--views", "14")["significance_pass"]
+    assert c["views"] == 14 and c["rccl_world_size"] == 2 and c["mask_identical_on_all_ranks"] is True
+    assert c["mask_equals_1gpu"] is True and c["counts_equal_1gpu"] is True and c["scores_bit_identical_1gpu"] is True and c["hits"] > 0
+    d = run("--steps", "3", "--warmup", "1", "--views", "8")          # the default line at N > 1: data-parallel step + the C4 leg
+    c4 = d["c4_significance_pass"]
+    assert c4["views"] == 200 and c4["views_per_rank"] == 100 and c4["mask_identical_on_all_ranks"] is True
+    assert c4["mask_equals_1gpu"] is True and c4["counts_equal_1gpu"] is True and c4["scores_bit_identical_1gpu"] is True
+    assert d["gradients_identical_on_all_ranks"] is True
