@@ -584,8 +584,17 @@ lg_sh_grad_from_rgb_kernel(int N, int M, int D, int V, const float* __restrict__
             else lg_backward_sh_jac(D, J, px, py, pz, cp, dRGB, dm, [&](int k, int c, float val) { dsh[k * 3 + c] += val; });
         }
         if (divisor != 1.0f) {
+            // a power of two (2, 4, 8 ranks): the reciprocal is exact and x * (1 / d) == x / d bit for bit -- one multiply instead of a
+            // correctly rounded division per coefficient; any other rank count divides, as torch's div_ does in the dense exchange
+            const uint32_t db = __float_as_uint(divisor);
+            if ((db & 0x007FFFFFu) == 0u) {
+                const float inv = 1.0f / divisor;
 #pragma unroll
-            for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = dsh[k] / divisor;
+                for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = dsh[k] * inv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < LG_SH_MAXF; k++) dsh[k] = dsh[k] / divisor;
+            }
         }
     }
     if (split && i < N) { dL_dshs[3 * (size_t)i] = dsh[0]; dL_dshs[3 * (size_t)i + 1] = dsh[1]; dL_dshs[3 * (size_t)i + 2] = dsh[2]; }

@@ -303,11 +303,18 @@ class RankOneSHExchange:
 
     def __init__(self, group=None, average=True, force=False):
         self.group, self.average, self.force = group, average, force
-        self.active = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if self.active else 1
         self.comm = None
         self.views = []          # (gathered dRGB [world, N, 3], gathered centres [world, 3], sh_degree, work or None)
         self.bytes_on_wire = 0
+
+    # (looked up at every use: the object may be created before init_process_group)
+    @property
+    def active(self):
+        return dist.is_available() and dist.is_initialized()
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if self.active else 1
 
     def add(self, drgb, campos, sh_degree):
         drgb = drgb.detach()
