@@ -79,6 +79,33 @@ def test_sh_gradients_rebuilt_from_drgb_are_the_bits_k9_writes(D, fused):
     assert float(res["dense"][1]["_features_rest"][:, (D + 1) ** 2 - 1:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("stored", [0, 1, 2])
+def test_sh_gradients_rebuilt_from_drgb_at_lower_stored_degrees(stored):
+    """M = 1, 4, 9 stored coefficients (a student after onedownSHdegree; a degree-0 model has no _features_rest rows at all)."""
+    from lightgaussian_amd.gaussian_renderer import render
+    from lightgaussian_amd import parallel
+    dev = torch.device(DEV)
+    W, H = 128, 80
+    g = _scene(N=1500, active=stored, stored=stored, seed=31)
+    M = (stored + 1) ** 2
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    gimg = torch.from_numpy(np.random.RandomState(8).randn(3, H, W).astype(np.float32)).to(dev)
+    cam = syn.orbit_camera(4, 7, W, H, radius=5.0).to(dev)
+    pc = g.to(dev).requires_grad_(True)
+    (render(cam, pc, syn.PipelineParams(), bg)["render"] * gimg).sum().backward()
+    sink = _Sink()
+    pc2 = g.to(dev).requires_grad_(True)
+    (render(cam, pc2, syn.PipelineParams(), bg, options={"sh_grad_sink": sink})["render"] * gimg).sum().backward()
+    drgb, cp, deg = sink.views[0]
+    g_dc, g_rest = parallel.sh_grad_from_rgb(pc2._xyz, cp.reshape(1, 3), drgb.unsqueeze(0), deg, M)
+    assert deg == stored and g_rest.shape == (1500, M - 1, 3)
+    assert torch.equal(g_dc, pc._features_dc.grad)
+    if M > 1:
+        assert torch.equal(g_rest, pc._features_rest.grad)
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        assert torch.equal(getattr(pc2, n).grad, getattr(pc, n).grad), n
+
+
 def test_two_views_summed_in_view_order_equal_the_accumulated_dense_gradient():
     from lightgaussian_amd.gaussian_renderer import render
     from lightgaussian_amd import parallel
