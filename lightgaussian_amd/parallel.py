@@ -269,7 +269,9 @@ def sh_grad_from_rgb(xyz, campos, drgb, sh_degree, M, divisor=1.0, out=None, acc
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        xyz_c, cam_c, drgb_c = xyz.detach().contiguous().float(), campos.contiguous().float(), drgb.contiguous()
+        # (the gathered buffer holds a view's [N, 3] block contiguously but the views 3 N + 3 floats apart: taken as it lies, no copy)
+        drgb_c = drgb if (drgb.dtype == torch.float32 and drgb.stride(-1) == 1 and drgb.stride(-2) == 3 and (V == 1 or drgb.stride(0) >= 3 * N)) else drgb.float().contiguous()
+        xyz_c, cam_c = xyz.detach().contiguous().float(), campos.contiguous().float()
         with torch.cuda.device(xyz.device):
             rc = lib.lg_sh_grad_from_rgb(N, M, int(sh_degree), V, C.c_void_p(xyz_c.data_ptr()), C.c_void_p(cam_c.data_ptr()), C.c_void_p(drgb_c.data_ptr()),
                                          int(drgb_c.stride(0)), float(divisor), 1 if accumulate else 0, C.c_void_p(g_dc.data_ptr()),
