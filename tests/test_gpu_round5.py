@@ -171,7 +171,9 @@ assert float(out[0][1].abs().sum()) > 0
 dist.destroy_process_group()
 print("RANK1_OK")
 '''
-    env = dict(os.environ, LG_ROOT=common.ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, LG_ROOT=common.ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RANK1_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
