@@ -21,7 +21,7 @@ Nothing in the trainers is edited; the glue hangs on four methods of the referen
                                              with one view per step -- in ranges overlapped with K9 (parallel.OverlappedGradAllReduce
                                              over lg_backward_chunked).  The round-4 form (dense SH gradients; only the rows some
                                              rank's camera saw: parallel.allreduce_gradients_visible) stays as the checker
-                                             (LG_DP_SH=dense, LG_DP_DENSE / visibility from note_render).
+                                             (configure(sh="dense") / configure(dense=True); visibility from note_render).
     GaussianModel.add_densification_stats    (train_densify_prune.py:175) the per-view statistics are summed over the ranks, so
                                              xyz_gradient_accum / denom -- and with them every densification decision -- are the same
                                              on every rank.
@@ -49,13 +49,47 @@ _STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(
 _GROUP_OF = {"_xyz": "xyz", "_features_dc": "f_dc", "_features_rest": "f_rest", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
 
 
+# Switches of the exchange.  They are set by configure() / install(**config) -- never read from the environment on the step's path
+# (a stray variable in a user's shell must not change what a training step exchanges).  The launcher (`python -m lightgaussian_amd.run`)
+# reads the LG_DP_* variables ONCE, at start-up, through config_from_env().
+#   sh         "rank1": SH gradients through parallel.RankOneSHExchange (default); "dense": all-reduced like the rest (the checker)
+#   force      exchange at world size 1 too (the RCCL code path on a 1-GPU box; tests)
+#   check_set  compare the set of parameters that hold a gradient across the ranks: True every step, False never, None = the schedule of _check_same_set
+#   dense      with sh="dense": one dense all-reduce of all six tensors instead of the visible-rows exchange
+#   check      verify the visible-rows precondition: True every step, False never, None = every 64th step
+#   overlap    install(): all-reduce the non-SH gradients in ranges behind K9 (parallel.OverlappedGradAllReduce)
+_DEFAULTS = {"sh": "rank1", "force": False, "check_set": None, "dense": False, "check": None, "overlap": False}
+_CONFIG = dict(_DEFAULTS)
+_ENV = {"LG_DP_SH": ("sh", lambda v: "dense" if v == "dense" else "rank1"), "LG_DP_FORCE": ("force", lambda v: v == "1"),
+        "LG_DP_CHECK_SET": ("check_set", lambda v: True if v == "1" else False if v == "0" else None), "LG_DP_DENSE": ("dense", lambda v: v == "1"),
+        "LG_DP_CHECK": ("check", lambda v: True if v == "1" else False if v == "0" else None), "LG_DP_OVERLAP": ("overlap", lambda v: v == "1")}
+
+
+def configure(**kw):
+    """Set switches of the exchange (see _DEFAULTS above); unknown names raise.  Returns the configuration now in force."""
+    for k, v in kw.items():
+        if k not in _DEFAULTS:
+            raise TypeError(f"dp.configure: unknown switch {k!r} (known: {sorted(_DEFAULTS)})")
+        if k == "sh" and v not in ("rank1", "dense"):
+            raise ValueError("dp.configure: sh must be 'rank1' or 'dense'")
+        _CONFIG[k] = v
+    return dict(_CONFIG)
+
+
+def config_from_env(env=None):
+    """The launcher's one read of the environment: LG_DP_SH=dense, LG_DP_FORCE=1, LG_DP_CHECK_SET=0|1, LG_DP_DENSE=1, LG_DP_CHECK=0|1,
+    LG_DP_OVERLAP=1 become configure() switches.  Called by lightgaussian_amd.run at start-up, nowhere else."""
+    env = os.environ if env is None else env
+    return configure(**{key: conv(env[name]) for name, (key, conv) in _ENV.items() if name in env})
+
+
 def sh_mode():
-    """"rank1" (default): SH gradients through parallel.RankOneSHExchange; "dense" (LG_DP_SH=dense): all-reduced like the rest."""
-    return "dense" if os.environ.get("LG_DP_SH", "rank1") == "dense" else "rank1"
+    """"rank1" (default): SH gradients through parallel.RankOneSHExchange; "dense" (configure(sh="dense")): all-reduced like the rest."""
+    return _CONFIG["sh"]
 
 
 def _forced():
-    return os.environ.get("LG_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
+    return bool(_CONFIG["force"]) and dist.is_available() and dist.is_initialized()
 
 
 def active():
@@ -130,7 +164,7 @@ def wrap_render(render_fn):
 def _sink_for(pc, override_color, pipe):
     """The RankOneSHExchange collecting this step's dRGB for the model `pc` (keyed by its _xyz tensor), or None when the render does
     not evaluate SH inside the rasterizer (override_color, convert_SHs_python), the model is not trainable, no exchange will follow,
-    or LG_DP_SH=dense."""
+    or configure(sh="dense")."""
     if sh_mode() != "rank1" or not (active() or _forced()):
         return None
     xyz = getattr(pc, "_xyz", None)
@@ -163,12 +197,12 @@ def _check_same_set(mask_bits, force=False):
     (mask, ~mask).  When: the comparison reads its result on the host, i.e. it drains the device and costs the step its run-ahead,
     so it is not made every step: on the first 8 steps, on every 64th, and on every step whose set differs from this rank's previous
     one (ranks that change together -- the legitimate case -- all compare; a rank that changes ALONE enters a collective the others do
-    not, which fails in the collective itself: no schedule short of every step can turn that into a clean error).  LG_DP_CHECK_SET=1:
-    every step (tests); LG_DP_CHECK_SET=0: never."""
-    mode = os.environ.get("LG_DP_CHECK_SET", "")
+    not, which fails in the collective itself: no schedule short of every step can turn that into a clean error).
+    configure(check_set=True): every step (tests); check_set=False: never."""
+    mode = _CONFIG["check_set"]
     n, prev = _STATE["steps"], _STATE.get("mask_prev")
     _STATE["mask_prev"] = mask_bits
-    if mode == "0" or not (mode == "1" or n <= 8 or n % 64 == 0 or (prev is not None and prev != mask_bits)):
+    if mode is False or not (mode is True or n <= 8 or n % 64 == 0 or (prev is not None and prev != mask_bits)):
         return
     group = _STATE["group"]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -192,7 +226,7 @@ def _take_visible(params):
     return hit
 
 
-def exchange_gradients(optimizer, check=None, force=False):
+def exchange_gradients(optimizer, check=None, force=None):
     """Average the gradients of the parameter groups of `optimizer` over the ranks (in place), right before its step().
 
     Which parameters: those that HAVE a gradient on this rank -- single-process Adam skips a group whose .grad is None, and the
@@ -200,9 +234,11 @@ def exchange_gradients(optimizer, check=None, force=False):
     between backward() and step()) -- plus the two SH groups when this step's renders went through the rank-one exchange
     (their .grad is None by design: the sink holds dRGB instead).  The set is compared across ranks (_check_same_set).
     How: SH groups rebuilt from the all-gathered dRGB (parallel.RankOneSHExchange.finish); the others by one bucketed dense
-    all-reduce -- or, when LG_DP_SH=dense and the step's renders were seen by note_render, the round-4 visible-rows exchange of all
-    six (check: verify its precondition -- rows outside this rank's visibility exactly zero -- default every 64th step and under
-    LG_DP_CHECK=1).  force: exchange at world size 1 too (the RCCL code path on a 1-GPU box)."""
+    all-reduce -- or, under configure(sh="dense") when the step's renders were seen by note_render, the round-4 visible-rows exchange
+    of all six (check: verify its precondition -- rows outside this rank's visibility exactly zero -- default: configure(check=...),
+    i.e. every 64th step).  force: exchange at world size 1 too (the RCCL code path on a 1-GPU box; default: configure(force=...))."""
+    if force is None:
+        force = bool(_CONFIG["force"])
     if not (active() or (force and dist.is_available() and dist.is_initialized())):
         return None
     groups = [(g.get("name"), p) for g in optimizer.param_groups for p in g["params"]]
@@ -212,7 +248,7 @@ def exchange_gradients(optimizer, check=None, force=False):
     sh_params = [by_name.get("f_dc"), by_name.get("f_rest")] if sink is not None else []
     if sink is not None and (sh_params[0] is None or sh_params[1] is None or by_name.get("xyz") is None):
         raise RuntimeError("data-parallel step: dRGB was collected for a model whose optimizer has no f_dc / f_rest / xyz groups "
-                           "(scene/gaussian_model.py:204-211 names them); use LG_DP_SH=dense")
+                           "(scene/gaussian_model.py:204-211 names them); use dp.configure(sh='dense')")
     have = [p for p in params if p.grad is not None and not any(p is q for q in sh_params)]
     _STATE["steps"] += 1
     mask_bits = sum(1 << i for i, p in enumerate(params[:16]) if p.grad is not None or any(p is q for q in sh_params))
@@ -233,7 +269,7 @@ def exchange_gradients(optimizer, check=None, force=False):
         info.update(mode="rank1_sh+dense", sh_bytes_on_wire=sink.bytes_on_wire)
     ov = _STATE.get("overlap")
     if ov is not None and ov.grads is not None:
-        # LG_DP_OVERLAP=1 / run.py --dp-overlap: the step's ONE rasterizer backward ran its per-Gaussian stage in ranges, and each range of the
+        # install(overlap=True) / run.py --dp-overlap: the step's ONE rasterizer backward ran its per-Gaussian stage in ranges, and each range of the
         # (non-SH) gradient tensors was all-reduced on a side stream while K9 computed the next one (parallel.OverlappedGradAllReduce over
         # lg_backward_chunked).  The reduced tensors replace what autograd put into the leaves; whatever the hook did not see -- the literal
         # getter pattern reports gradients of the ACTIVATED tensors, which are not parameters -- goes through the dense all-reduce below.
@@ -253,15 +289,15 @@ def exchange_gradients(optimizer, check=None, force=False):
         return info
     N = have[0].shape[0]
     rows_ok = sink is None and vis is not None and vis.shape[0] == N and all(p.grad.shape[0] == N for p in have) and len(have) == len(params)
-    if rows_ok and os.environ.get("LG_DP_DENSE", "0") != "1":
+    if rows_ok and not _CONFIG["dense"]:
         if check is None:
-            check = os.environ.get("LG_DP_CHECK", "") == "1" or (os.environ.get("LG_DP_CHECK", "") != "0" and _STATE["steps"] % 64 == 1)
+            check = _CONFIG["check"] is True or (_CONFIG["check"] is None and _STATE["steps"] % 64 == 1)
         if check:
             hidden = ~vis.reshape(-1).bool()
             for p in have:
                 if bool((p.grad.reshape(N, -1)[hidden] != 0).any()):
                     raise RuntimeError("data-parallel step: a gradient row of a Gaussian no render of this step saw is non-zero; the "
-                                       "visible-rows exchange would leave it unreduced (use LG_DP_DENSE=1)")
+                                       "visible-rows exchange would leave it unreduced (use dp.configure(dense=True))")
         k, _ = parallel.allreduce_gradients_visible(have, vis, group=_STATE["group"], force=force)
         _STATE["rows"] += k
         world = dist.get_world_size(_STATE["group"])
@@ -283,8 +319,8 @@ def wrap_optimizer(optimizer):
     inner = optimizer.step
 
     def step(*a, **kw):
-        # (LG_DP_FORCE=1: exchange at world size 1 too -- the RCCL code path of a 1-GPU box, tests/test_gpu_dp_runner.py)
-        exchange_gradients(optimizer, force=os.environ.get("LG_DP_FORCE", "0") == "1")
+        # (configure(force=True): exchange at world size 1 too -- the RCCL code path of a 1-GPU box, tests/test_gpu_dp_runner.py)
+        exchange_gradients(optimizer)
         with _STATE["lock"]:
             # visibility / dRGB recorded for models that are never stepped, or whose _xyz was replaced by a prune / densify between
             # backward() and step(): do not keep the old tensors alive
@@ -312,14 +348,17 @@ def shard_cameras(cams, rank, world):
     return mine if mine else list(cams)
 
 
-def install(gaussian_model_cls=None, scene_cls=None, group=None, overlap=None):
+def install(gaussian_model_cls=None, scene_cls=None, group=None, overlap=None, **config):
     """Hang the data-parallel glue on the reference's classes (see the module docstring).  Safe to call at world size 1 (every hook
     degenerates to the original behaviour).  uninstall() restores the classes.
-    overlap (default: env LG_DP_OVERLAP=1): all-reduce the non-SH gradients in ranges behind K9 instead of after backward() returns
-    (one rasterizer backward per optimizer step, as all three reference trainers have it; a second one before step() raises)."""
+    overlap (default: configure(overlap=...)): all-reduce the non-SH gradients in ranges behind K9 instead of after backward() returns
+    (one rasterizer backward per optimizer step, as all three reference trainers have it; a second one before step() raises).
+    **config: further configure() switches."""
     _STATE["group"] = group
+    if config:
+        configure(**config)
     if overlap is None:
-        overlap = os.environ.get("LG_DP_OVERLAP", "0") == "1"
+        overlap = bool(_CONFIG["overlap"])
     if overlap and (active() or _forced()) and _STATE.get("overlap") is None:
         _STATE["overlap"] = parallel.OverlappedGradAllReduce(group, chunks=4)
         _STATE["overlap"].__enter__()
@@ -399,6 +438,7 @@ def uninstall():
         _STATE["overlap"].__exit__(None, None, None)
         _STATE["overlap"] = None
     _STATE["group"] = None
+    _CONFIG.update(_DEFAULTS)
 
 
 def stats():

@@ -84,7 +84,7 @@ def allreduce_gradients_visible(params, visible, group=None, average=True, force
     the order in which the ring sums the ranks' contributions (identical at world size 2).
     params: tensors [N, ...] with .grad; visible: bool [N] = visibility_filter of this rank's render(s) of the step (union over a
     camera batch).  Costs one host sync (the size of the union).  Returns (rows exchanged, N).
-    PRECONDITIONS (not checked here; lightgaussian_amd.dp.exchange_gradients checks them, the second one under LG_DP_CHECK=1):
+    PRECONDITIONS (not checked here; lightgaussian_amd.dp.exchange_gradients checks them, the second one under dp.configure(check=True)):
     every rank passes the same parameters and each of them has a gradient (a parameter whose .grad is None on one rank only would
     change that rank's flat buffer size and mismatch the collective); `visible` covers EVERY view accumulated into .grad since it
     was last cleared, and nothing but those views contributed -- a regulariser on opacity or scale leaves non-zero values in rows

@@ -343,6 +343,7 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     distributed = no_patch = verbose = adam = lazy = no_timing = False
     backend = "nccl"
+    dp_overlap = False
     while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
         flag = argv.pop(0)
         if flag == "--distributed":
@@ -352,7 +353,7 @@ def main(argv=None):
         elif flag == "--verbose":
             verbose = True
         elif flag == "--dp-overlap":              # with --distributed: non-SH gradients all-reduced in ranges behind K9 (dp.install(overlap=True))
-            os.environ["LG_DP_OVERLAP"] = "1"
+            dp_overlap = True
         elif flag == "--fused-adam":
             adam = True
         elif flag == "--lazy-loss":
@@ -391,12 +392,17 @@ def main(argv=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         # (under a launcher -- RANK in the environment -- the group is created at world size 1 as well: harmless, every dp hook
-        #  stays passive there unless LG_DP_FORCE=1 sends the exchange through the collectives: the RCCL path on a 1-GPU box)
+        #  stays passive there unless dp.configure(force=True) sends the exchange through the collectives: the RCCL path on a 1-GPU box)
         if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             else:
                 dist.init_process_group(backend)
+        # the launcher's ONE read of the LG_DP_* variables (dp.config_from_env); the step's path never looks at the environment
+        from . import dp
+        dp.config_from_env()
+        if dp_overlap:
+            dp.configure(overlap=True)
     if adam:
         fused_adam(True)
     if lazy:

@@ -4,7 +4,7 @@ The SH-coefficient gradient of one view is the outer product basis(dir) (x) dRGB
 centre instead of all-reducing [N, 16, 3], and rebuild the sum locally.  A stand-in render with the rasterizer's contract (option
 `sh_grad_sink`: the backward hands dL/d(rgb) to the sink and returns None for the coefficient gradients) drives the unmodified
 trainer loop of tests/test_dp_trainer.py.  Checked:
-  * three Adam steps with the rank-one exchange leave the parameters of the dense exchange (LG_DP_SH=dense), bit for bit, on both ranks;
+  * three Adam steps with the rank-one exchange leave the parameters of the dense exchange (`dp.configure(sh="dense")`), bit for bit, on both ranks;
   * a camera batch of two views per rank and step (gradient accumulation): equal to 1e-6 (another summation order), ranks bit-equal;
   * a parameter group without a gradient on every rank (train_densify_prune.py:194-197: reset_opacity() between backward() and
     step(), ADVICE r4) is skipped like single-process Adam skips it -- no raise, ranks stay equal; a group missing on ONE rank raises;
@@ -16,6 +16,7 @@ import random
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -149,9 +150,9 @@ def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None
 
 
 def _run(mode, views_per_step=1, reset_at=None, overlap=False):
-    os.environ["LG_DP_SH"] = mode
-    dp.uninstall()
-    dp.install(Model, Scene, overlap=overlap)
+    dp.uninstall()                                     # (also puts every switch back to its default)
+    # check_set=True: compare the parameter sets on every step (default: first steps, every 64th, on a change)
+    dp.install(Model, Scene, overlap=overlap, sh=mode, check=False, check_set=True)
     random.seed(0); torch.manual_seed(0)
     model, scene = Model(), Scene()
     model.training_setup(None)
@@ -163,8 +164,6 @@ def _run(mode, views_per_step=1, reset_at=None, overlap=False):
 
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    os.environ["LG_DP_CHECK"] = "0"
-    os.environ["LG_DP_CHECK_SET"] = "1"                # compare the parameter sets on every step (default: first steps, every 64th, on a change)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dp.install(Model, Scene)
@@ -241,3 +240,22 @@ def test_the_cpu_restatement_of_sh_grad_from_rgb_is_the_gradient_of_eval_sh():
             out = parallel.sh_grad_from_rgb(xyz, cams[:2], drgb[:2], deg, Mst, divisor=1.0)
             out = parallel.sh_grad_from_rgb(xyz, cams[2:], drgb[2:], deg, Mst, divisor=2.0, out=out, accumulate=True)
             assert torch.equal(torch.cat(out, 1), got), (deg, Mst)
+
+
+def test_switches_are_configuration_not_environment(monkeypatch):
+    """The exchange's switches live in dp.configure(); the environment is read once by the launcher (dp.config_from_env), never on the
+    step's path: a stray LG_DP_* variable in a shell changes nothing for a process that did not ask for it."""
+    dp.uninstall()
+    monkeypatch.setenv("LG_DP_SH", "dense")
+    monkeypatch.setenv("LG_DP_FORCE", "1")
+    assert dp.sh_mode() == "rank1" and not dp._CONFIG["force"]
+    cfg = dp.config_from_env()                                   # what `python -m lightgaussian_amd.run` does at start-up
+    assert cfg["sh"] == "dense" and cfg["force"] is True and cfg["check_set"] is None and dp.sh_mode() == "dense"
+    assert dp.config_from_env({"LG_DP_CHECK_SET": "0", "LG_DP_CHECK": "1", "LG_DP_OVERLAP": "1"})["check_set"] is False
+    assert dp._CONFIG["check"] is True and dp._CONFIG["overlap"] is True
+    with pytest.raises(TypeError):
+        dp.configure(shh="dense")
+    with pytest.raises(ValueError):
+        dp.configure(sh="sparse")
+    dp.uninstall()                                               # back to the defaults
+    assert dp._CONFIG == dp._DEFAULTS and dp.sh_mode() == "rank1"

@@ -123,7 +123,7 @@ def _worker(rank, world, port, out_dir):
         from lightgaussian_amd import prune as lg_prune
         assert lg_prune._train_cameras(scene) == full               # the significance pass sees the whole list
         log = []
-        os.environ["LG_DP_CHECK"] = "1"
+        dp.configure(check=True)
         trainer_loop(model, scene, dp.wrap_render(render), STEPS, log)
         st = dp.stats()
         assert st["steps"] == STEPS and st["dense_steps"] == 0 and 0 < st["rows_exchanged"] < STEPS * N

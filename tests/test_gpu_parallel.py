@@ -137,7 +137,7 @@ def test_visible_rows_exchange_and_the_data_parallel_optimizer_step_through_rccl
         (pkg["render"] * gimg).sum().backward()
         nvis = int(pkg["visibility_filter"].sum())
         info = dp.exchange_gradients(opt, check=True, force=True)
-        # (no LG_DP_FORCE in the environment: the render wrapper hands out no dRGB sink, so this is the round-4 exchange -- all six tensors,
+        # (dp.configure(force=True) not set: the render wrapper hands out no dRGB sink, so this is the round-4 exchange -- all six tensors,
         #  visible rows -- which round 5 keeps as the checker of the rank-one SH exchange; that one runs in test_gpu_dp_runner / test_gpu_round5)
         assert info == {"rows": nvis, "of": g.num, "mode": "visible", "params": 6} and 0 < nvis < g.num
         for n in NAMES:
