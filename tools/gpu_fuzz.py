@@ -25,13 +25,10 @@ if os.environ.get("LG_FUZZ_LONG"):     # serial | auto | parallel: walk of multi
 if os.environ.get("LG_FUZZ_SYNC"):     # off | validated | nowait
     from lightgaussian_amd import rasterizer as _r
     _r.set_option("sync_free", {"off": False, "validated": "validated"}[os.environ["LG_FUZZ_SYNC"]])
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-only = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-bad = 0
-for t in range(trials):
+def make_trial(t):
+    """Trial t of phase 1: (kwargs for the rasterizer as torch tensors, the same as numpy, a description, the trial's RandomState --
+    positioned where the gradient image is drawn next)."""
     rs = np.random.RandomState(777 + 7919 * t)          # per-trial stream: `only` reruns exactly one trial
-    if only >= 0 and t != only:
-        continue
     N = int(rs.choice([1, 2, 7, 64, 65, 300, 2000, 9000]))
     W, H = int(rs.choice([1, 5, 16, 17, 33, 100, 257])), int(rs.choice([1, 3, 16, 31, 64, 130]))
     stored = int(rs.randint(0, 4))
@@ -48,6 +45,21 @@ for t in range(trials):
     kw["sh_degree"] = deg
     kw["scale_modifier"] = mod
     npk = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    return kw, npk, dict(N=N, W=W, H=H, stored=stored, deg=deg, mod=mod, scale=scale), rs
+
+
+if __name__ != "__main__":
+    trials = 0                                           # imported (tools/gpu_fuzz_one.py): only make_trial is wanted
+else:
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+only = int(sys.argv[2]) if len(sys.argv) > 2 and __name__ == "__main__" else -1
+first = int(os.environ.get("LG_FUZZ_FIRST", "0"))      # trials first .. first + trials - 1: campaigns beyond the round script's 0 .. 149
+bad = 0
+for t in range(first, first + trials):
+    if only >= 0 and t != only:
+        continue
+    kw, npk, meta, rs = make_trial(t)
+    N, W, H, stored, deg, mod, scale = (meta[k] for k in ("N", "W", "H", "stored", "deg", "mod", "scale"))
     ref = oracle.forward(count=True, **npk)
     out = gpu_common.hip_forward_backward(kw, count=True)
     why = []
@@ -86,9 +98,9 @@ bad2 = 0
 if os.environ.get("LG_FUZZ_NARROW"):   # keys laid out as if only 40 bits were available (option narrow_key)
     from lightgaussian_amd import rasterizer as _r
     _r.set_option("narrow_key", True)
-n2 = int(os.environ.get("LG_FUZZ_N2", max(10, trials // 4)))   # LG_FUZZ_N2: size of the fused-getter phase on its own
-for t in range(n2):
-    rs = np.random.RandomState(991 + 104729 * t)
+n2 = 0 if __name__ != "__main__" else int(os.environ.get("LG_FUZZ_N2", max(10, trials // 4)))   # LG_FUZZ_N2: size of the fused-getter phase on its own
+for t in range(first, first + n2):
+    rs = np.random.RandomState((991 + 104729 * t) % (2 ** 32))
     N = int(rs.choice([1, 63, 64, 65, 500, 4099, 20000]))
     W, H = int(rs.choice([16, 33, 100, 257])), int(rs.choice([16, 31, 64, 130]))
     deg = int(rs.randint(0, 4))
@@ -121,6 +133,6 @@ for t in range(n2):
     if why:
         bad2 += 1
         print(f"FUSED MISMATCH trial {t}: N={N} {W}x{H} deg={act}/{deg} mod={mod2}: {', '.join(why)}")
-print(f"fuzz: {trials} trials, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches")
-bad += bad2
-sys.exit(1 if bad else 0)
+if __name__ == "__main__":
+    print(f"fuzz: trials {first}..{first + trials - 1}, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches")
+    sys.exit(1 if bad + bad2 else 0)
