@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Extended seeded fuzz (not part of the test suite: ~1-2 minutes): random scene statistics incl. tiny images, single
 Gaussians, depth slabs (long runs of equal sorted key bits), huge splats; hit counts / scores / radii / count-render image
-bit-identical to the float oracle, training render within 1e-5, gradients within max(1e-4, 3 x fp32-oracle noise floor) of the float64 oracle."""
+bit-identical to the float oracle, training render within 1e-5, gradients within max(1e-4, 3 x fp32-oracle noise floor) of the float64 oracle.
+Phase 2: getters inside the kernels against the literal getter pattern.  Phase 3 (LG_FUZZ_N3): the significance-only pass with the serial and
+the parallel long-tile walk at short segment lengths, counts and scores bit-identical to the oracle.  LG_FUZZ_FIRST: first trial number."""
 import math
 import os
 import sys
@@ -133,6 +135,46 @@ for t in range(first, first + n2):
     if why:
         bad2 += 1
         print(f"FUSED MISMATCH trial {t}: N={N} {W}x{H} deg={act}/{deg} mod={mod2}: {', '.join(why)}")
+# ---- phase 3: the significance-only pass (colours skipped, as prune_list_sharded issues it) with the serial walk and with the parallel
+# ---- long-tile walk (lg_count_seg / _rewalk / _fixup, round 5) at short segment lengths: counts and scores against the oracle, bit for bit
+def count_pass(kw, options):
+    import ctypes as C
+    from lightgaussian_amd import _lib, rasterizer
+    from lightgaussian_amd.rasterizer import GaussianRasterizationSettings
+    t = {k: (v.detach().to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    rset = GaussianRasterizationSettings(t["H"], t["W"], t["tanfovx"], t["tanfovy"], t["bg"], t.get("scale_modifier", 1.0), t["viewmatrix"], t["projmatrix"],
+                                         t["sh_degree"], t["campos"], False, False, True)
+    opts = rasterizer.resolve_options(dict(options, skip_color_in_count=True, sync_free=False))
+    call = rasterizer._Call(rset, t["means3D"], t.get("shs"), t.get("colors_precomp"), t["opacities"], t.get("scales"), t.get("rotations"), t.get("cov3D_precomp"),
+                            exact=True, opts=opts)
+    lib = _lib.load()
+    _color, radii, cnt, score, _geom, binning, _img, R = rasterizer._native_forward(lib, call, rset, True)
+    meta = torch.zeros(16, dtype=torch.int32, device=dev)
+    _lib.check(lib.lg_debug_view_meta(C.byref(call.view), binning.data_ptr(), int(R), meta.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return cnt.cpu().numpy(), score.cpu().numpy(), meta.cpu().numpy().view(np.uint32)
+
+
+bad3 = par_items = fixups = 0
+n3 = 0 if __name__ != "__main__" else int(os.environ.get("LG_FUZZ_N3", trials // 2))
+for t in range(first, first + n3):
+    kw, npk, meta, rs = make_trial(t)
+    S, wide = int(rs.choice([64, 128, 256])), bool(rs.rand() < 0.5)
+    ref = oracle.forward(count=True, **npk)
+    why = []
+    with torch.no_grad():
+        for tag, opt in (("serial", dict(long_tiles="serial")), ("parallel", dict(long_tiles="parallel", count_wide_band=wide))):
+            c, sc, m = count_pass(kw, dict(opt, segment_length=S))
+            if tag == "parallel":
+                # (a view without instances launches no work-list workgroup: its meta words are whatever the allocator left there)
+                ran = bool(0 < m[4] < (1 << 24) and m[2] == S and m[1] > 2 * S)
+                par_items += int(ran); fixups += int(m[5]) if ran else 0
+            if not np.array_equal(c, ref.count): why.append(f"{tag}:count({int((c != ref.count).sum())})")
+            if not np.array_equal(sc.view(np.uint32), ref.score.view(np.uint32)): why.append(f"{tag}:score")
+    if why:
+        bad3 += 1
+        print(f"COUNT MISMATCH trial {t}: N={meta['N']} {meta['W']}x{meta['H']} S={S} wide={wide}: {', '.join(why)}")
 if __name__ == "__main__":
-    print(f"fuzz: trials {first}..{first + trials - 1}, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches")
-    sys.exit(1 if bad + bad2 else 0)
+    print(f"fuzz: trials {first}..{first + trials - 1}, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches; "
+          f"significance-only phase: {n3} trials ({par_items} with multi-segment lists in the parallel walk, {fixups} exact fix-ups), {bad3} mismatches")
+    sys.exit(1 if bad + bad2 + bad3 else 0)
