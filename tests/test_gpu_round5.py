@@ -342,26 +342,31 @@ def test_bench_data_parallel_step_with_two_ranks_on_one_gpu(tmp_path):
     assert vis["gradients_identical_on_all_ranks"] is True and vis["gradient_sha256"] == dn["gradient_sha256"]
 
 
-def test_bench_c4_pass_with_two_ranks_on_one_gpu(tmp_path):
-    """BASELINE configs[3] in miniature, for real at world size 2 (two processes on this box's one GPU, collectives over gloo): the sharded
-    significance pass of `bench.py --mode count` (int32 count all-reduce, round-wise ordered all_to_all of the scores, all_gather) and the
-    C4 leg of the default line: counts, ordered scores and the prune mask equal to the single-rank pass recomputed on rank 0."""
+def _bench_ranks_on_one_gpu(world, *extra):
+    """`bench.py --gpus world` as `world` processes on this box's one GPU (LG_BENCH_SHARE_GPU=1, collectives over gloo) -> its JSON line."""
     import json
     import socket
     import subprocess
     import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LG_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(common.ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--n-gaussians", "150000", "--width", "480", "--height", "272",
+           "--scale", "0.02", "--no-cpu-baseline", "--no-roofline", "--no-literal", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=common.ROOT, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_c4_pass_with_two_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] in miniature, for real at world size 2 (two processes on this box's one GPU, collectives over gloo): the sharded
+    significance pass of `bench.py --mode count` (int32 count all-reduce, round-wise ordered all_to_all of the scores, all_gather) and the
+    C4 leg of the default line: counts, ordered scores and the prune mask equal to the single-rank pass recomputed on rank 0."""
     def run(*extra):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        env = dict(os.environ, LG_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k, None)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n-gaussians", "150000", "--width", "480", "--height", "272",
-               "--scale", "0.02", "--no-cpu-baseline", "--no-roofline", "--no-literal", *extra]
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=common.ROOT, timeout=900)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
-        return json.loads(lines[0])
+        return _bench_ranks_on_one_gpu(2, *extra)
     c = run("--mode", "count", "--steps", "7", "--warmup", "2", "--views", "14")["significance_pass"]
     assert c["views"] == 14 and c["rccl_world_size"] == 2 and c["mask_identical_on_all_ranks"] is True
     assert c["mask_equals_1gpu"] is True and c["counts_equal_1gpu"] is True and c["scores_bit_identical_1gpu"] is True and c["hits"] > 0
@@ -370,3 +375,29 @@ def test_bench_c4_pass_with_two_ranks_on_one_gpu(tmp_path):
     assert c4["views"] == 200 and c4["views_per_rank"] == 100 and c4["mask_identical_on_all_ranks"] is True
     assert c4["mask_equals_1gpu"] is True and c4["counts_equal_1gpu"] is True and c4["scores_bit_identical_1gpu"] is True
     assert d["gradients_identical_on_all_ranks"] is True
+
+
+def test_bench_with_four_ranks_on_one_gpu(tmp_path):
+    """The same at world size FOUR (the mask must equal the 1-GPU mask at 1 / 2 / 4 / 8 ranks): four processes, the real kernels,
+    the round-wise all_to_all of the score rows with three peers, 7 views per rank; and the data-parallel step with three peers per
+    all-gather -- every rank ends the step with the same gradient bits, with the rank-one SH exchange and with the dense all-reduce (at
+    four ranks the two associate the sum differently: equal to rounding, not bit for bit)."""
+    c = _bench_ranks_on_one_gpu(4, "--mode", "count", "--steps", "7", "--warmup", "1", "--views", "28")["significance_pass"]
+    assert c["views"] == 28 and c["rccl_world_size"] == 4 and c["mask_identical_on_all_ranks"] is True
+    assert c["mask_equals_1gpu"] is True and c["counts_equal_1gpu"] is True and c["scores_bit_identical_1gpu"] is True and c["hits"] > 0
+    d = _bench_ranks_on_one_gpu(4, "--steps", "3", "--warmup", "1", "--views", "8", "--no-c4-leg")
+    assert d["n_gpus"] == 4 and d["gradients_identical_on_all_ranks"] is True and d["data_parallel"]["exchange"].startswith("SH gradients rebuilt")
+    assert d["data_parallel"]["rccl_world_size"] == 4
+    dn = _bench_ranks_on_one_gpu(4, "--steps", "3", "--warmup", "1", "--views", "8", "--no-c4-leg", "--dense-allreduce")
+    assert dn["gradients_identical_on_all_ranks"] is True and dn["data_parallel"]["exchange"].startswith("dense tensors")
+    assert 0 < d["data_parallel"]["bytes_on_wire_per_step"] < 0.5 * dn["data_parallel"]["bytes_on_wire_per_step"]
+
+
+def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
+    """World size EIGHT -- the driver's node -- in the same test mode: the sharded significance pass (seven peers per all_to_all round, 7 views
+    per rank) gives the 1-GPU counts, ordered scores and mask; the data-parallel step leaves the same gradient bits on all eight ranks."""
+    c = _bench_ranks_on_one_gpu(8, "--mode", "count", "--steps", "7", "--warmup", "1", "--views", "56")["significance_pass"]
+    assert c["views"] == 56 and c["rccl_world_size"] == 8 and c["mask_identical_on_all_ranks"] is True
+    assert c["mask_equals_1gpu"] is True and c["counts_equal_1gpu"] is True and c["scores_bit_identical_1gpu"] is True and c["hits"] > 0
+    d = _bench_ranks_on_one_gpu(8, "--steps", "2", "--warmup", "1", "--views", "8", "--no-c4-leg")
+    assert d["n_gpus"] == 8 and d["gradients_identical_on_all_ranks"] is True and d["data_parallel"]["rccl_world_size"] == 8
