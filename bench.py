@@ -647,12 +647,12 @@ def main():
             del c1, i1, m1
         del cnt, imp, mask_all
         extra["c4_significance_pass"] = c4
-    if dp_step and args.mode == "fwdbwd" and dist.is_initialized():
+    if dp_step and args.mode in ("fwdbwd", "distill") and dist.is_initialized():
         # every rank holds the same averaged gradients after a step: compare a digest of the last step's (all six tensors) across the ranks
         import hashlib
         step(0)                    # (one more step on a FIXED camera: the digest is a function of the inputs, not of how many steps the ~1 s loop ran)
         h, per = hashlib.sha256(), []
-        for p in params:
+        for p in (params if args.mode == "fwdbwd" else sparams):          # (distill: the student's parameters are what the step trains)
             b = (p.grad.detach() + 0.0).contiguous().cpu().numpy().tobytes()          # (+ 0.0: -0.0 and +0.0 hash alike -- equal values, equal digest)
             h.update(b); per.append(hashlib.sha256(b).hexdigest()[:16])
         digs = [None] * dist.get_world_size()

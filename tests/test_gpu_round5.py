@@ -401,3 +401,16 @@ def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
     assert c["mask_equals_1gpu"] is True and c["counts_equal_1gpu"] is True and c["scores_bit_identical_1gpu"] is True and c["hits"] > 0
     d = _bench_ranks_on_one_gpu(8, "--steps", "2", "--warmup", "1", "--views", "8", "--no-c4-leg")
     assert d["n_gpus"] == 8 and d["gradients_identical_on_all_ranks"] is True and d["data_parallel"]["rccl_world_size"] == 8
+
+
+def test_bench_distill_step_with_two_and_eight_ranks_on_one_gpu(tmp_path):
+    """C5's step (student forward + backward at SH degree D - 1 against the teacher's forward, `bench.py --mode distill --gpus W`) in the same
+    test mode: the student's gradients after the exchange are the same bits on every rank; at two ranks the rank-one SH exchange and the
+    dense all-reduce leave the same bits."""
+    a = _bench_ranks_on_one_gpu(2, "--mode", "distill", "--steps", "2", "--warmup", "1", "--views", "8")
+    b = _bench_ranks_on_one_gpu(2, "--mode", "distill", "--steps", "2", "--warmup", "1", "--views", "8", "--dense-allreduce")
+    assert a["gradients_identical_on_all_ranks"] is True and b["gradients_identical_on_all_ranks"] is True
+    assert a["gradient_sha256"] == b["gradient_sha256"], (a["gradient_sha256_per_tensor"], b["gradient_sha256_per_tensor"])
+    assert a["data_parallel"]["bytes_on_wire_per_step"] < b["data_parallel"]["bytes_on_wire_per_step"]
+    c = _bench_ranks_on_one_gpu(8, "--mode", "distill", "--steps", "2", "--warmup", "1", "--views", "8")
+    assert c["n_gpus"] == 8 and c["gradients_identical_on_all_ranks"] is True
