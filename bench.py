@@ -449,8 +449,14 @@ def main():
             if collectives and dp_step:
                 exchange(sparams, spkg["visibility_filter"], sink, student)
         else:
+            # --mode count outside prune_list_sharded (the per-kernel bracket pass): the SAME variant the timed pass runs -- getters
+            # hoisted, colours skipped -- so that `kernels_ms` and the hipEvent bracket describe lg_blend_fwd<COUNT, no colour> and a K1
+            # without SH reads (until round 5 this leg ran the image-returning count_render: K1 0.197 instead of ~0.10 ms in the line)
             with torch.no_grad():
-                count_render(cams[k], pc, pipe, bg)
+                if sh_sink.get("frozen") is None:
+                    from lightgaussian_amd.prune import _FrozenGetters
+                    sh_sink["frozen"] = _FrozenGetters(pc)
+                count_render(cams[k], sh_sink["frozen"], pipe, bg, options={"skip_color_in_count": True})
 
     def make_batch_runner(K, host_threads=False):
         """camera batch > 1: K independent views in flight on K HIP streams, each stream with its own parameter
@@ -736,6 +742,12 @@ def main():
         rasterizer.set_option("profile", False)
         _lib.profile_reset()
         ab = algorithmic_bytes(N, vis, R, P, M)
+        if args.mode == "count":
+            # the significance-only pass as prune_list_sharded runs it: K1 reads no SH rows and keeps nothing for a backward, the blend
+            # writes no per-pixel outputs -- the bytes the kernels HAVE to move, not SURVEY 8d's figure for a count_render that also returns the
+            # image (that one stays in the line as bytes_model.survey_8d)
+            ab["preprocess"] = 16 * N + 64 * vis
+            ab["blend_fwd_count"] = 44 * R + 8 * N
         per_kernel = {name: {"avg_ms": tot / max(n, 1), "launches_per_step": n / nprof} for name, (tot, n) in prof.items()}
         dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches_per_step"])
         bracket_ms = per_kernel[dom]["avg_ms"]
@@ -768,7 +780,8 @@ def main():
                                 "76R+20P (SURVEY 8d: instance re-read 40 + gradient scatter 36; per pixel 20)", 76 * R + 20 * P),
                   "blend_fwd": ("44R+20P (DESIGN 5: per instance sorted key 8 + blend record 36; per pixel 20)",
                                 "40R+20P (SURVEY 8d: blend gather 40 per instance; per pixel 20)", 40 * R + 20 * P),
-                  "blend_fwd_count": ("44R+20P+8N (DESIGN 5)", "40R+20P+8N (SURVEY 8d)", 40 * R + 20 * P + 8 * N)}.get(dom)
+                  "blend_fwd_count": ("44R+8N (DESIGN 5; significance-only pass: sorted key 8 + blend record 36 per instance, count + score 8 per Gaussian, no per-pixel outputs)",
+                                      "40R+20P+8N (SURVEY 8d: count_render that also returns the image)", 40 * R + 20 * P + 8 * N)}.get(dom)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_symbol": sym, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(time_ms, 4),
