@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--replicas", action="store_true", help="fwdbwd, N > 1: no gradient exchange (N independent replicas, the round-3 behaviour); for comparison only")
     ap.add_argument("--force-collectives", action="store_true", help="run the data-parallel exchange and the C4 leg even at world size 1 (needs a process group: launch "
                     "through torch.distributed.run --nproc-per-node 1): the RCCL code path on a 1-GPU box")
+    ap.add_argument("--step-trace", type=int, default=0, help="diagnostic (fwdbwd / fwd, N = 1): instead of the timed loops, run this many steps and print the "
+                                                                 "rate of every window of 25 steps (host clock and hipEvents) to stderr -- shows transients")
     ap.add_argument("--no-c4-leg", action="store_true", help="fwdbwd, N > 1: skip the C4 significance pass that rides in the same JSON line")
     ap.add_argument("--n-gaussians", type=int, default=3_000_000)
     ap.add_argument("--width", type=int, default=1920)
@@ -512,6 +514,14 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
+    # Host hygiene before any timed loop: CPython's cyclic collector would otherwise run a FULL collection over the start-up heap (torch,
+    # numpy, the scene: ~35 ms on this box) once, some hundred steps into the run -- the host stops issuing, the device drains, and a ~1 s
+    # measurement reads 4.5 % low (found with --step-trace: 1.435 ms per step in every window of 25 steps but one at 3.0).  gc.freeze()
+    # moves what exists now into the permanent generation: later collections only look at what the steps themselves allocate.  No work is
+    # skipped; a trainer does the same once after set-up (`python -m lightgaussian_amd.run` does).
+    import gc
+    gc.collect()
+    gc.freeze()
     if args.mode == "count":
         # the significance pass of config C4: every rank renders `steps` views of a (steps*world)-camera list with
         # count_render, then the RCCL reduction (int all-reduce + ordered score exchange); getters evaluated once
@@ -578,6 +588,30 @@ def main():
         elapsed = time.perf_counter() - t0
         extra["views_in_flight"] = args.views_in_flight
     else:
+        if args.step_trace > 0 and world == 1:
+            # diagnostic: where in a run the time goes -- per window of 25 steps: host time to ISSUE them, device time between the events
+            win, evs, host = 25, [], []
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e0.record(); evs.append(e0); host.append(time.perf_counter())
+            per, seg, col = [], [], []
+            for i in range(args.step_trace):
+                ts = time.perf_counter()
+                step(i)
+                per.append(time.perf_counter() - ts)
+                seg.append(torch.cuda.memory_stats(dev).get("segment.all.allocated", 0))
+                col.append(sum(g["collections"] for g in gc.get_stats()[1:]))
+                if (i + 1) % win == 0:
+                    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e); host.append(time.perf_counter())
+            torch.cuda.synchronize()
+            tend = time.perf_counter()
+            print(f"[step-trace] {args.step_trace} steps, windows of {win}: (steps, issue ms/step on the host, device ms/step, views/s by the device, gc counts)", file=sys.stderr)
+            for w in range(1, len(evs)):
+                dms = evs[w - 1].elapsed_time(evs[w]) / win
+                print(f"[step-trace] {w * win:5d} {(host[w] - host[w - 1]) * 1e3 / win:7.3f} {dms:7.3f} {1e3 / dms:8.1f} {gc.get_count()}", file=sys.stderr)
+            for i in sorted(range(len(per)), key=lambda k: -per[k])[:6]:
+                print(f"[step-trace] slow step {i}: {per[i] * 1e3:.2f} ms on the host (camera {view_of_step(my_views, i * KV)}); allocator segments "
+                      f"{seg[i - 1] if i else 0} -> {seg[i]}, gen1+gen2 collections {col[i - 1] if i else 0} -> {col[i]}", file=sys.stderr)
+            print(f"[step-trace] total {(tend - host[0]):.3f} s -> {args.step_trace / (tend - host[0]):.1f} views/s; gc stats {gc.get_stats()}", file=sys.stderr)
         for i in range(args.warmup):
             step(i)
         barrier()
@@ -722,6 +756,7 @@ def main():
                        "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_lazy": "0.8*L1 + 0.2*(1-SSIM), fused HIP kernels, the reference's two calls + formula on lazy scalars (loss_utils.set_lazy)",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
+                       "host": "gc.collect() + gc.freeze() once after set-up: no full collection of the start-up heap inside the timed loops (DESIGN 22.6)",
                        "parallelism": (f"dp{world}: {KV} camera(s) per rank per step, gradients averaged over RCCL before the next step" if dp_step else
                                        f"camera-shard x{world}: counts all-reduced, scores exchanged in view order (prune_list_sharded)" if (args.mode == "count" and world > 1) else
                                        f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},
