@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--replicas", action="store_true", help="fwdbwd, N > 1: no gradient exchange (N independent replicas, the round-3 behaviour); for comparison only")
     ap.add_argument("--force-collectives", action="store_true", help="run the data-parallel exchange and the C4 leg even at world size 1 (needs a process group: launch "
                     "through torch.distributed.run --nproc-per-node 1): the RCCL code path on a 1-GPU box")
+    ap.add_argument("--no-gc-freeze", action="store_true", help="diagnostic: leave CPython's start-up heap collectable (the behaviour before round 5's last change: one "
+                                                                "~35 ms full collection a few hundred steps into the run; DESIGN 22.6)")
     ap.add_argument("--step-trace", type=int, default=0, help="diagnostic (fwdbwd / fwd, N = 1): instead of the timed loops, run this many steps and print the "
                                                                  "rate of every window of 25 steps (host clock and hipEvents) to stderr -- shows transients")
     ap.add_argument("--no-c4-leg", action="store_true", help="fwdbwd, N > 1: skip the C4 significance pass that rides in the same JSON line")
@@ -520,8 +522,9 @@ def main():
     # moves what exists now into the permanent generation: later collections only look at what the steps themselves allocate.  No work is
     # skipped; a trainer does the same once after set-up (`python -m lightgaussian_amd.run` does).
     import gc
-    gc.collect()
-    gc.freeze()
+    if not args.no_gc_freeze:
+        gc.collect()
+        gc.freeze()
     if args.mode == "count":
         # the significance pass of config C4: every rank renders `steps` views of a (steps*world)-camera list with
         # count_render, then the RCCL reduction (int all-reduce + ordered score exchange); getters evaluated once
@@ -756,7 +759,8 @@ def main():
                        "loss": {"l1": "L1 (HIP, lg_loss_forward/backward with LG_FLAG_L1_ONLY)", "l1_torch": "L1 (torch ops)", "l1_dssim": "0.8*L1 + 0.2*(1-SSIM), fused HIP lg_loss_forward/backward",
                                 "l1_dssim_lazy": "0.8*L1 + 0.2*(1-SSIM), fused HIP kernels, the reference's two calls + formula on lazy scalars (loss_utils.set_lazy)",
                                 "l1_dssim_torch": "0.8*L1 + 0.2*(1-SSIM), torch conv2d (reference pattern)"}[args.loss] if args.mode == "fwdbwd" else None,
-                       "host": "gc.collect() + gc.freeze() once after set-up: no full collection of the start-up heap inside the timed loops (DESIGN 22.6)",
+                       "host": ("gc.collect() + gc.freeze() once after set-up: no full collection of the start-up heap inside the timed loops (DESIGN 22.6)"
+                                if not args.no_gc_freeze else "--no-gc-freeze: start-up heap left collectable (diagnostic)"),
                        "parallelism": (f"dp{world}: {KV} camera(s) per rank per step, gradients averaged over RCCL before the next step" if dp_step else
                                        f"camera-shard x{world}: counts all-reduced, scores exchanged in view order (prune_list_sharded)" if (args.mode == "count" and world > 1) else
                                        f"camera-shard x{world}" + (" (independent replicas, no collective)" if world > 1 else ""))},
