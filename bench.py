@@ -87,6 +87,8 @@ def parse():
                     help="fwdbwd loss: l1 (the metric's definition, SURVEY 8d C3; HIP lg_loss_forward with LG_FLAG_L1_ONLY), l1_torch (the same "
                          "in torch ops), l1_dssim = 0.8*L1 + 0.2*(1-SSIM) on the fused HIP "
                          "kernels (loss_utils, SURVEY 8f row 1), l1_dssim_torch = the same loss as the reference computes it (torch conv2d)")
+    ap.add_argument("--weight-policy", choices=["opacity", "one", "alpha", "alpha_t"], default="opacity",
+                    help="significance passes (--mode count, the C4 leg): what one hit adds to important_score (rasterizer option weight_policy)")
     ap.add_argument("--count-streams", type=int, default=4, help="--mode count: views in flight per rank (host threads x HIP streams)")
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="fwdbwd/fwd: render this many independent views concurrently (host threads x HIP streams, gradients "
@@ -460,7 +462,7 @@ def main():
                 if sh_sink.get("frozen") is None:
                     from lightgaussian_amd.prune import _FrozenGetters
                     sh_sink["frozen"] = _FrozenGetters(pc)
-                count_render(cams[k], sh_sink["frozen"], pipe, bg, options={"skip_color_in_count": True})
+                count_render(cams[k], sh_sink["frozen"], pipe, bg, options={"skip_color_in_count": True, "weight_policy": args.weight_policy})
 
     def make_batch_runner(K, host_threads=False):
         """camera batch > 1: K independent views in flight on K HIP streams, each stream with its own parameter
@@ -531,12 +533,12 @@ def main():
         def cam_list(n):
             return [syn.orbit_camera(k % args.views, args.views, W, H).to(dev) for k in range(n)]
         with torch.no_grad():
-            prune_list_sharded(pc, cam_list(max(args.warmup, 2) * world), pipe, bg, force_collectives=world > 1, streams=args.count_streams)
+            prune_list_sharded(pc, cam_list(max(args.warmup, 2) * world), pipe, bg, force_collectives=world > 1, streams=args.count_streams, weight_policy=args.weight_policy)
         cl = cam_list(args.steps * world)
         barrier()
         t0 = time.perf_counter()
         with torch.no_grad():
-            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1, streams=args.count_streams)
+            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=world > 1, streams=args.count_streams, weight_policy=args.weight_policy)
         barrier()
         elapsed = time.perf_counter() - t0
         from lightgaussian_amd import prune as _prune
@@ -546,7 +548,7 @@ def main():
             mask_all = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1))
         extra["significance_pass"] = {"views": args.steps * world, "seconds": round(elapsed, 4),
                                       "score_checksum": float(imp.double().sum().item()), "hits": int(cnt.sum().item()),
-                                      "views_in_flight_per_rank": args.count_streams, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                                      "views_in_flight_per_rank": args.count_streams, "weight_policy": args.weight_policy, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
                                       "prune_ratio": 0.66, "v_pow": 0.1, "pruned": int(mask_all.sum().item()), "mask_sha256": mask_digest(mask_all)}
         if world > 1:
             digests = [None] * world
@@ -555,7 +557,7 @@ def main():
         if rank == 0 and world > 1 and not args.no_verify_1gpu:
             # the same camera list on ONE rank (the plain single-process loop): the mask must not depend on the GPU count
             with torch.no_grad():
-                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, local_only=True)
+                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, weight_policy=args.weight_policy, local_only=True)
                 m1 = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, i1, 0.1))
             extra["significance_pass"].update({"mask_equals_1gpu": bool(torch.equal(m1, mask_all)), "counts_equal_1gpu": bool(torch.equal(c1, cnt)),
                                                "scores_bit_identical_1gpu": bool(torch.equal(i1, imp)), "mask_sha256_1gpu": mask_digest(m1)})
@@ -666,10 +668,10 @@ def main():
         cl = [syn.orbit_camera(k % args.views, args.views, W, H).to(dev) for k in range(nviews)]
         st = {}
         with torch.no_grad():
-            prune_list_sharded(pc, cl[: 4 * world], pipe, bg, force_collectives=True, streams=args.count_streams)      # warm-up
+            prune_list_sharded(pc, cl[: 4 * world], pipe, bg, force_collectives=True, streams=args.count_streams, weight_policy=args.weight_policy)      # warm-up
             barrier()
             t0 = time.perf_counter()
-            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=True, streams=args.count_streams, stats=st)
+            cnt, imp = prune_list_sharded(pc, cl, pipe, bg, force_collectives=True, streams=args.count_streams, weight_policy=args.weight_policy, stats=st)
             barrier()
             c4_s = time.perf_counter() - t0
             mask_all = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, imp, 0.1))
@@ -683,7 +685,7 @@ def main():
         c4["mask_identical_on_all_ranks"] = len(set(digests)) == 1
         if rank == 0:
             with torch.no_grad():
-                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, local_only=True)
+                c1, i1 = prune_list_sharded(pc, cl, pipe, bg, streams=args.count_streams, weight_policy=args.weight_policy, local_only=True)
                 m1 = _prune.prune_mask(0.66, _prune.calculate_v_imp_score(pc, i1, 0.1))
             c4.update({"mask_sha256_1gpu": mask_digest(m1), "mask_equals_1gpu": bool(torch.equal(m1, mask_all)), "counts_equal_1gpu": bool(torch.equal(c1, cnt)),
                        "scores_bit_identical_1gpu": bool(torch.equal(i1, imp))})
@@ -795,7 +797,8 @@ def main():
         # library now loaded (lg_build_id) on this workload; otherwise the live in-library hipEvent bracket (which reads ~14 %
         # above rocprof on the VALU-bound blend kernels).  Both are always printed.
         sym = {"blend_bwd": "lg_blend_bwd_splat" if (args.bwd_splat_parallel and not args.exact_exp) else "lg_blend_bwd<false>" if not args.exact_exp else "lg_blend_bwd<true>",
-               "blend_fwd": "lg_blend_fwd<false, false, false, true>", "blend_fwd_count": "lg_blend_fwd<true, false, true, false>",
+               "blend_fwd": "lg_blend_fwd<false, 0, false, true>",
+               "blend_fwd_count": "lg_blend_fwd<true, %d, true, false>" % {"opacity": 0, "one": 0, "alpha": 2, "alpha_t": 3}[args.weight_policy],
                "preprocess": "lg_preprocess<true, true>", "preprocess_bwd": "lg_preprocess_bwd<true, true>"}.get(dom)
         prof_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_profile_{args.mode}.json")
         stats_file = f"profiles/{PROFILE_ROUND}_{args.mode}_kernel_stats.csv"

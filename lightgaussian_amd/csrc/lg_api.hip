@@ -154,6 +154,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     const bool count = out_count != nullptr;
     if (count && !out_score) return fail(LG_ERR_INVALID_ARGUMENT, "count needs score");
     if (count && (weight_policy < 0 || weight_policy > 3)) return fail(LG_ERR_INVALID_ARGUMENT, "bad weight policy");
+    // per-hit weights are summed in Q24.40 per view: a Gaussian can collect at most 0.99 per pixel
+    if (count && weight_policy >= LG_WEIGHT_ALPHA && (int64_t)v->image_width * v->image_height > (1ll << 24))
+        return fail(LG_ERR_INVALID_ARGUMENT, "ALPHA / ALPHA_T weights: images beyond 2^24 pixels overflow the Q24.40 per-view sums");
     hipStream_t stream = (hipStream_t)stream_p;
     const bool debug = v->flags & LG_FLAG_DEBUG, prof = v->flags & LG_FLAG_PROFILE, fast = v->flags & LG_FLAG_FAST_EXP;
     const int N = g->N, W = v->image_width, H = v->image_height;
@@ -339,18 +342,23 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         // significance-only pass has no backward)
         const bool nocolor_pass = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);
         dim3 grid(ntiles_pad + ((nocolor_pass && !par_long) ? 0 : 1)), block(256);     // (the parallel long-tile walk needs the par_work list)
-#define LAUNCH_FWD(CNT, FS, EX)                                                                                                      \
-    lg_blend_fwd<CNT, FS, EX><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg,     \
-                                                         out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived)
-        const bool fs = count && (weight_policy == LG_WEIGHT_ALPHA || weight_policy == LG_WEIGHT_ALPHA_T);
+#define LAUNCH_FWD(CNT, FS, EX, COL)                                                                                                 \
+    lg_blend_fwd<CNT, FS, EX, COL><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, \
+                                                         out_color, img.final_T, img.n_contrib, out_count, (unsigned long long*)bin.keys_in, geo.tinfo, (uint32_t)cap, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived)
+        // per-hit weights (ALPHA / ALPHA_T): the kernel is instantiated per policy and adds {count | Q8.40 weight} words into the instances'
+        // pre-sort slots -- the radix sort's input buffer, free since lg_tile_sort and cleared here
+        const int fs = !count ? 0 : weight_policy == LG_WEIGHT_ALPHA ? 2 : weight_policy == LG_WEIGHT_ALPHA_T ? 3 : 0;
+        if (fs && cap > 0 && N > 0) HIP_TRY(lg_zero_async(bin.keys_in, (size_t)cap * 8, stream));
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
-        if (!count) { if (fast) LAUNCH_FWD(false, false, false); else LAUNCH_FWD(false, false, true); }
+        if (!count) { if (fast) LAUNCH_FWD(false, 0, false, true); else LAUNCH_FWD(false, 0, true, true); }
         else if (nocolor) {
-            if (fs) lg_blend_fwd<true, true, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived);
-            else lg_blend_fwd<true, false, true, false><<<grid, block, 0, stream>>>(W, H, gx, ntiles, ntiles_pad, bin.ranges, bin.entries, gid_mask, geo.rec, v->bg, out_color, img.final_T, img.n_contrib, out_count, out_score, weight_policy, S, bin.ckpt, bin.work, bin.meta, bin.par_work, geo.counters, long_mode, bin.par_arrived);
+            if (fs == 2) LAUNCH_FWD(true, LG_W_ALPHA, true, false);
+            else if (fs == 3) LAUNCH_FWD(true, LG_W_ALPHA_T, true, false);
+            else LAUNCH_FWD(true, 0, true, false);
         }
-        else if (!fs) { if (fast) LAUNCH_FWD(true, false, false); else LAUNCH_FWD(true, false, true); }
-        else { if (fast) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, true, true); }
+        else if (!fs) { if (fast) LAUNCH_FWD(true, 0, false, true); else LAUNCH_FWD(true, 0, true, true); }
+        else if (fs == 2) { if (fast) LAUNCH_FWD(true, LG_W_ALPHA, false, true); else LAUNCH_FWD(true, LG_W_ALPHA, true, true); }
+        else { if (fast) LAUNCH_FWD(true, LG_W_ALPHA_T, false, true); else LAUNCH_FWD(true, LG_W_ALPHA_T, true, true); }
 #undef LAUNCH_FWD
     }
     KCHECK("lg_blend_fwd");
@@ -380,9 +388,12 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
                                                       out_color, img.final_T, img.n_contrib, bin.ckpt, bin.ckpt_last);
         KCHECK("lg_blend_fwd_long");
     }
-    if (count && N > 0 && (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)) {
+    if (count && N > 0) {
         ProfScope ps(prof, "score", stream);
-        lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
+        if (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)
+            lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
+        else
+            lg_score_slots<<<(N + 255) / 256, 256, 0, stream>>>(N, geo.touched, geo.tinfo, (const unsigned long long*)bin.keys_in, (uint32_t)cap, out_count, out_score);
         KCHECK("lg_score_kernel");
     }
     if (debug && N > 0) {

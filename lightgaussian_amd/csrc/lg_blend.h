@@ -149,17 +149,68 @@ __device__ __forceinline__ uint64_t fwd_pair_m(const float4& a, const float4& b,
     return cm;
 }
 
-// K6 / K6c: forward blend
-template <bool COUNT, bool FSCORE, bool EXACT, bool COLOR = true>
+// Significance weights that differ from hit to hit (LG_W_ALPHA: alpha, LG_W_ALPHA_T: alpha T) are accumulated in 64-bit FIXED POINT,
+// Q24.40: every hit's fp32 weight w (3.9e-7 <= w <= 0.99) is rounded to the nearest multiple of 2^-40 (ties to even; exact for
+// w >= 2^-17) and the integers are added -- associative, so the per-view sum does not depend on the order the waves' atomics land in:
+// bit-reproducible run to run, equal to the oracle's sequential loop, and any partition of the views over ranks gives the same scores.
+// The quantisation is one double-precision add: (double) w + 4096 has its unit in the last place at 2^-40, so the low 40 bits of the
+// sum's mantissa ARE round(w 2^40); adding the bit patterns as integers and subtracting n x bits(4096.0) leaves the sum of the n
+// quantised weights (no carry can reach the exponent: 64 x 2^40 < 2^52).
+// (lg_fix40_bits / LG_FIX_MAGIC / lg_fix40_score: lg_math.h, pinned on the CPU by tests/test_math_harness.py)
+//
+// The 64 x (entries) matrix of a wave's weights is transposed through LDS, 8 entries at a time: every pair step stores one row of fp32
+// weights (ds_write_b32, 64 lanes; 0 where the pixel does not contribute); after 8 rows lane 8 r + s quantises and adds columns 8 s ..
+// 8 s + 7 of row r (two ds_read_b128, 8 x {cvt, add}, 7 integer adds) and three DPP steps inside each group of 8 lanes (quad xor 1, quad
+// xor 2, half-row mirror) leave the row total in all 8: ~4 vector instructions per entry where a DPP wave reduction per entry costs 7 (+ a
+// readlane), and no cross-lane traffic in the pair step itself.  Lane 8 r + c keeps the total of chunk c: lane l ends up owning compacted
+// entry 8 (l & 7) + (l >> 3) of the batch (LG_WQ_OWNER) -- its hit count (ballot popcount of the pair step) AND its weight total.
+//
+// Where the totals go (round 6, measured -- tools/ubench/atomic_rate.hip, profiles/r06_call_b.log): a random-address global atomic costs the
+// device ~40 ns of its atomic pipe whatever its width (4.8 M per view = 0.19 ms: hidden behind the 0.3 ms of arithmetic when there is ONE
+// per (wave, entry), as in the integer-weight variant; a second one per (wave, entry) -- count[id] and a 64-bit sum[id] -- made the kernel
+// atomic-bound, 0.33 -> 0.61 ms).  So count and weight total travel in ONE 64-bit atomic: per (tile, Gaussian) INSTANCE the ranges are
+// small -- at most 256 hits, weight below 256 -- and {count : 16 | Q8.40 : 48} fits a word.  The word lives at the instance's pre-sort slot
+// (lg_slot_of: a closed form of the Gaussian's tile rectangle; the radix sort's input buffer, free by now and cleared, holds the slots) and
+// lg_score_slots sums every Gaussian's consecutive slots into out_count / out_score -- no atomics there.
+#define LG_WQ_ROWS 8
+#define LG_WQ_STRIDE 68                               // row stride in floats (64 lanes + 16 bytes of skew)
+#define LG_WQ_OWNER(lane) (8u * ((lane) & 7u) + ((lane) >> 3))
+#define LG_SLOT_COUNT_SHIFT 48
+__device__ __forceinline__ uint64_t lg_wq_rowsum(const float* wq, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float4* src = reinterpret_cast<const float4*>(wq + (lane >> 3) * LG_WQ_STRIDE + (lane & 7u) * 8u);
+    const float4 x0 = src[0], x1 = src[1];
+    // this lane's eight columns; modulo 2^64, minus 8 x bits(4096.0): exactly the sum of 8 quantised weights, below 2^43
+    const uint64_t s = (((lg_fix40_bits(x0.x) + lg_fix40_bits(x0.y)) + (lg_fix40_bits(x0.z) + lg_fix40_bits(x0.w))) +
+                        ((lg_fix40_bits(x1.x) + lg_fix40_bits(x1.y)) + (lg_fix40_bits(x1.z) + lg_fix40_bits(x1.w)))) - 8ull * LG_FIX_MAGIC;
+    // across the 8 lanes of the row in two 32-bit limbs (24 + 19 bits: eight of them cannot carry), so that each step is ONE
+    // v_add_u32_dpp per limb (hipcc has no 64-bit DPP add: two v_mov_b32_dpp + two 64-bit adds per step)
+    uint32_t lo = (uint32_t)s & 0xFFFFFFu, hi = (uint32_t)(s >> 24);
+    lo = dpp_add_u32<0xB1>(lo); hi = dpp_add_u32<0xB1>(hi);          // quad_perm [1,0,3,2]
+    lo = dpp_add_u32<0x4E>(lo); hi = dpp_add_u32<0x4E>(hi);          // quad_perm [2,3,0,1]
+    lo = dpp_add_u32<0x141>(lo); hi = dpp_add_u32<0x141>(hi);        // row_half_mirror: lane i <-> 7 - i of each group of 8 (the other quad)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // (the next chunk overwrites the rows)
+    return ((uint64_t)hi << 24) + lo;
+}
+
+// K6 / K6c: forward blend.  FSCORE: 0, or the per-hit weight policy (LG_W_ALPHA / LG_W_ALPHA_T) accumulated into fix[] (Q24.40)
+template <bool COUNT, int FSCORE, bool EXACT, bool COLOR = true>
 __global__ void __launch_bounds__(256)
 lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __restrict__ ranges,
              const uint64_t* __restrict__ entries, uint32_t gid_mask, const float4* __restrict__ rec, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             int32_t* __restrict__ count, float* __restrict__ fscore, int weight_policy, int S, float4* __restrict__ ckpt,
+             int32_t* __restrict__ count, unsigned long long* __restrict__ slots, const uint4* __restrict__ tinfo, uint32_t slot_cap,
+             int S, float4* __restrict__ ckpt,
              uint2* __restrict__ work, uint32_t* __restrict__ meta, uint2* __restrict__ par_work, const uint32_t* __restrict__ counters,
              int long_mode, uint32_t* __restrict__ par_arrived)
 {
+    static_assert(FSCORE == 0 || ((FSCORE == LG_W_ALPHA || FSCORE == LG_W_ALPHA_T) && COUNT), "FSCORE is 0 or a per-hit weight policy of the count variant");
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
+    __shared__ __attribute__((aligned(16))) float wq[FSCORE ? 4 : 1][FSCORE ? LG_WQ_ROWS * LG_WQ_STRIDE : 1];
     // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
     // view's own numbers (counters[3] = its instance count), evaluated identically by every workgroup
     const uint32_t par_min = lg_par_min(long_mode, S, counters[3], ntiles);
@@ -243,13 +294,16 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 // and the walk below is a counted loop (was: pop the lowest set bit of the hit mask per step -- s_ff1, two 64-bit
                 // scalar ops, an add and a v_mov per hit)
                 r2.y = __uint_as_float(idx - range.x + 1u);
+                // per-hit weights: the entry's pre-sort slot rides where the box half-extent hy was (read by nothing after the block test)
+                if (FSCORE) r2.z = __uint_as_float(lg_slot_of(tinfo[__float_as_uint(r2.w) & LG_ID_MASK], tx, ty));
                 q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
             }
             __builtin_amdgcn_wave_barrier();
             int mycnt = 0;
-            float myf = 0.0f;
+            uint64_t myfix = 0ull;
             const uint32_t nhit = (uint32_t)__popcll(mask);
-            auto pair = [&](uint32_t j) {
+            const uint32_t owned = FSCORE ? LG_WQ_OWNER(lane) : lane;       // the compacted entry whose totals this lane collects
+            auto pair = [&](uint32_t j, float* wrow) {
                 const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
                 float alpha = 0.0f, Tprev = T, w = 0.0f;
 #ifdef LG_K6_BOOL_DONE
@@ -261,26 +315,38 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 #endif
                 if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
                 if (COUNT) {
-                    if (lane == j) mycnt = (int)__popcll(cm);
-                    if (FSCORE) {
-                        float wv = res ? (weight_policy == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
-                        wv = wave_sum_to_lane63(wv);
-                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), 63));
-                        if (lane == j) myf = tot;
-                    }
+                    if (owned == j) mycnt = (int)__popcll(cm);
+                    if (FSCORE) *wrow = res ? (FSCORE == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
                 }
             };
             // (round 5, measured and rejected: two pair steps per trip of this loop -- written out by hand, hipcc refuses `#pragma unroll` over the
             //  convergent ballots behind the guard's branch -- to halve the loop control, three of the nine scalar instructions of a pair step:
             //  K6 0.2661 / 0.2651 -> 0.2638 / 0.2602 ms bracketed, the count variant 0.365 / 0.3595 -> 0.3616 / 0.3636: noise level, 62 VGPRs instead of 56.)
-            for (uint32_t j = 0; j < nhit; j++) pair(j);
+            if (FSCORE) {
+                // chunks of LG_WQ_ROWS pair steps, each leaving one row of quantised weights; then the rows are summed (lg_wq_rowsum).  (Rows past
+                // the end of a last, partial chunk hold older weights: their totals go to lanes whose entry is >= nhit, which issue nothing.)
+                for (uint32_t c0 = 0; c0 < nhit; c0 += LG_WQ_ROWS) {
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)LG_WQ_ROWS, nhit - c0));
+                    float* wrow = &wq[wave][lane];
+                    for (uint32_t jj = 0; jj < m; jj++, wrow += LG_WQ_STRIDE) pair(c0 + jj, wrow);
+                    const uint64_t tot = lg_wq_rowsum(wq[wave], lane);
+                    if ((lane & 7u) == (c0 >> 3)) myfix = tot;
+                }
+            } else {
+                for (uint32_t j = 0; j < nhit; j++) pair(j, nullptr);
+            }
             if (COUNT) {
                 // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
                 // (round 5 ablation, profiles/r05_call_count_band.log: without these atomics the kernel takes 287 us instead of 328)
-                if (lane < nhit && mycnt > 0) {
-                    const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
-                    atomicAdd(&count[id], mycnt);
-                    if (FSCORE) atomicAdd(&fscore[id], myf);
+                if (!FSCORE) {
+                    if (lane < nhit && mycnt > 0) {
+                        const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
+                        atomicAdd(&count[id], mycnt);
+                    }
+                } else if (owned < nhit && mycnt > 0) {
+                    // {count : 16 | Q8.40 : 48} of this wave's 8 x 8 block, into the (tile, Gaussian) instance's slot
+                    const uint32_t slot = __float_as_uint(q2[wave][owned].z);
+                    if (slot < slot_cap) atomicAdd(&slots[slot], ((unsigned long long)(uint32_t)mycnt << LG_SLOT_COUNT_SHIFT) + myfix);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -849,6 +915,35 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
     if (i >= N) return;
     const int c = count[i];
     score[i] = c > 0 ? lg_seqsum32(weight ? weight[i] : 1.0f, (uint32_t)c) : 0.0f;
+}
+// per-view count and score of the ALPHA / ALPHA_T policies: every Gaussian sums the {count : 16 | Q8.40 : 48} words of its own instances
+// (consecutive pre-sort slots, tinfo.w .. + touched) -- integer adds, any order -- and rounds the Q24.40 total to fp32 ONCE (nearest even),
+// times 2^-40 (exact).  A lane walks up to LG_SLOT_SOLO slots itself; Gaussians with more (screen-filling splats) are summed by the whole wave.
+#define LG_SLOT_SOLO 16u
+__global__ void __launch_bounds__(256)
+lg_score_slots(int N, const uint32_t* __restrict__ touched, const uint4* __restrict__ tinfo, const unsigned long long* __restrict__ slots,
+               uint32_t slot_cap, int32_t* __restrict__ count, float* __restrict__ score)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n = 0, base = 0;
+    if (i < N) { n = touched[i]; if (n) base = tinfo[i].w; }
+    if (base >= slot_cap || n > slot_cap - base) n = 0;           // (a view that outgrew its capacity is void anyway)
+    uint64_t fix = 0; uint32_t cnt = 0;
+    if (n <= LG_SLOT_SOLO)
+        for (uint32_t k = 0; k < n; k++) { const uint64_t w = slots[base + k]; cnt += (uint32_t)(w >> LG_SLOT_COUNT_SHIFT); fix += w & ((1ull << LG_SLOT_COUNT_SHIFT) - 1ull); }
+    uint64_t big = __ballot(n > LG_SLOT_SOLO);
+    while (big) {                                                 // wave-uniform
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)n, src), bb = (uint32_t)__builtin_amdgcn_readlane((int)base, src);
+        uint64_t f = 0; uint32_t c = 0;
+        for (uint32_t k = lane; k < bn; k += 64u) { const uint64_t w = slots[bb + k]; c += (uint32_t)(w >> LG_SLOT_COUNT_SHIFT); f += w & ((1ull << LG_SLOT_COUNT_SHIFT) - 1ull); }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) { c += __shfl_xor(c, sft, 64); f += __shfl_xor(f, sft, 64); }
+        if ((int)lane == src) { cnt = c; fix = f; }
+    }
+    if (i < N) { count[i] = (int32_t)cnt; score[i] = lg_fix40_score(fix); }
 }
 
 // ------------------------------------------------------------------------------------------------

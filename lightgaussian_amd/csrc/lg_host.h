@@ -179,7 +179,8 @@ struct BinView {
     uint32_t* ckpt_last;            // [2 (R / S + 1)][256] last contributing list position per (segment, pixel): pass 1 -> join of
                                     //     the parallel long-tile forward (lg_blend_fwd_seg / _scan / _rewalk)
     uint64_t* entries;              // [R] sorted list entries = the sorted keys (tile | depth | id); the low bits_for(N) bits are the Gaussian id
-    uint64_t* keys_in;              // [R] radix-sort input; free after the sort: ping-pong buffer of lg_tile_sort_long / of lg_tile_ranges' long runs
+    uint64_t* keys_in;              // [R] radix-sort input; free after the sort: ping-pong buffer of lg_tile_sort_long / of lg_tile_ranges' long runs,
+                                    //     then -- per-hit weight policies -- the per-instance {count | weight} words of lg_blend_fwd<COUNT, FSCORE>
     void* sort_temp; size_t sort_temp_bytes; size_t total;
 };
 static int bits_for(uint32_t n) // smallest b with 2^b >= n

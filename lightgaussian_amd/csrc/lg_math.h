@@ -54,6 +54,18 @@ LG_HD float lg_exp(float x)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Q24.40 fixed point of the per-hit significance weights (LG_W_ALPHA / LG_W_ALPHA_T).
+// lg_fix40_bits(w): bit pattern of (double) w + 4096.  For 0 <= w < 4096 the sum lies in [2^12, 2^13), where a double's unit in the
+// last place is 2^-40: the IEEE addition rounds w to the nearest multiple of 2^-40 (ties to even) and the low 40 bits of the
+// mantissa field are that multiple.  LG_FIX_MAGIC = bits(4096.0); bits - LG_FIX_MAGIC = round(w 2^40).
+// lg_fix40_score(q): the per-view sum as fp32 -- ONE rounding (nearest even) of the integer, then an exact scaling by 2^-40.
+#define LG_FIX_FRAC_BITS 40
+#define LG_FIX_MAGIC 0x40B0000000000000ull
+LG_HD uint64_t lg_fix40_bits(float w) { union { double d; uint64_t u; } c; c.d = (double)w + 4096.0; return c.u; }
+LG_HD uint64_t lg_fix40_quant(float w) { return lg_fix40_bits(w) - LG_FIX_MAGIC; }
+LG_HD float lg_fix40_score(uint64_t q) { return (float)q * 0x1p-40f; }
+
+// ---------------------------------------------------------------------------------------------
 // seqsum32(w, c): the float obtained by c sequential additions of w starting from 0 -- i.e. what
 // c atomicAdd(float*, w) calls produce (all addends equal, so order independent).  O(#binades)
 // instead of O(c): inside one binade every step adds the same multiple of the ulp, so the run

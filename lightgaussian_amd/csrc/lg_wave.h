@@ -31,3 +31,10 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+
+// integer add across lanes through DPP (one v_add_u32_dpp): every lane receives v + v[partner]
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}

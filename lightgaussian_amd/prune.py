@@ -297,7 +297,7 @@ def _ordered_sum(rows, out=None):
 
 
 def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ordered", count_fn=count_render, force_collectives=False,
-                       streams=4, block=24, local_only=False, host_threads=False, stats=None):
+                       streams=4, block=24, local_only=False, host_threads=False, stats=None, weight_policy=None):
     """Camera-sharded prune_list.  Every rank passes the SAME full camera list and the same Gaussians; returns the same
     (gaussian_list, imp_list) on every rank, bit-identical to the reference loop (mode="ordered") for every world size.
     Without an initialised process group (or at world size 1 unless force_collectives, or with local_only=True inside a
@@ -306,6 +306,10 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
              stream with exact forwards); 1 = the plain sequential loop.
     stats:   optional dict; receives "exchange_seconds" (time of this rank's collectives: device events on the current stream for HIP
              tensors, wall clock for CPU tensors), "collectives" and "world".
+    weight_policy: per-hit weight of important_score for the forwards of THIS pass ("opacity" | "one" | "alpha" | "alpha_t" or a
+             _lib.WEIGHT_* number; None = the rasterizer option in force, default "opacity").  Every policy gives per-view scores that
+             are pure functions of the view (integer-derived or Q24.40 fixed-point sums, no float atomics), so the ordered exchange
+             below makes scores and masks bit-identical across world sizes for all four.
     block:   views per rank per round.  The pass keeps a running sum and absorbs the views round by round in the reference's
              order, so scratch memory is O(block * N) floats per rank whatever the number of views (the reference's loop is
              O(N); the first version of this function held all V score vectors, O(V * N)).
@@ -313,8 +317,12 @@ def prune_list_sharded(gaussians, scene, pipe, background, group=None, mode="ord
     4 -> 1326 views/s; round 2, one host thread: 3 -> 1540, 4 -> 1579, 6 -> 1513 (heavy-tailed scene: 1336 / 1412 / 1299)."""
     # the pass discards the images: its forwards do not read 192 B of SH per Gaussian per view (a per-call option of the
     # forwards THIS pass issues -- the process defaults are not touched, other threads render as before)
+    opts = {"skip_color_in_count": True}
+    if weight_policy is not None:
+        from . import rasterizer
+        opts["weight_policy"] = rasterizer.weight_policy_id(weight_policy)
     return _prune_list_sharded(gaussians, scene, pipe, background, group, mode, count_fn, force_collectives, streams, max(1, int(block)),
-                               local_only, host_threads, {"skip_color_in_count": True}, stats)
+                               local_only, host_threads, opts, stats)
 
 
 class _CollectiveTimer:

@@ -52,7 +52,23 @@ _LONG_TILES = ("serial", "auto", "parallel")
 _tls = threading.local()
 
 
+WEIGHT_POLICIES = {"one": _lib.WEIGHT_ONE, "opacity": _lib.WEIGHT_OPACITY, "alpha": _lib.WEIGHT_ALPHA, "alpha_t": _lib.WEIGHT_ALPHA_T}
+
+
+def weight_policy_id(value):
+    """_lib.WEIGHT_* of a policy given by number or by name ("one" | "opacity" | "alpha" | "alpha_t")."""
+    if isinstance(value, str):
+        if value.lower() not in WEIGHT_POLICIES:
+            raise ValueError(f"weight_policy must be one of {tuple(WEIGHT_POLICIES)} (or a _lib.WEIGHT_* number)")
+        return WEIGHT_POLICIES[value.lower()]
+    if int(value) not in WEIGHT_POLICIES.values():
+        raise ValueError(f"weight_policy {value!r}: not a _lib.WEIGHT_* value")
+    return int(value)
+
+
 def _validate(name, value):
+    if name == "weight_policy":
+        weight_policy_id(value)
     if name == "long_tiles" and value not in _LONG_TILES:
         raise ValueError(f"long_tiles must be one of {_LONG_TILES}")
     if name == "segment_length" and (int(value) < 0 or (int(value) != 0 and (int(value) < 64 or int(value) % 64))):
@@ -62,7 +78,11 @@ def _validate(name, value):
 def set_option(name, value):
     """Process default of one knob; returns the previous value.  (Per call: `options=` of GaussianRasterizer / render /
     count_render; per thread: `with rasterizer.options(...)`.)
-    weight_policy: _lib.WEIGHT_* (default OPACITY = LightGaussian's sigma_j weight);
+    weight_policy: what one (pixel, Gaussian) hit adds to important_score -- _lib.WEIGHT_* or its name: "opacity" (default: sigma_j,
+              LightGaussian's published Global Significance Score), "one" (score == hit count), "alpha" (the blending weight
+              alpha_j of the hit) or "alpha_t" (alpha_j T, the hit's share of the pixel).  Every policy is deterministic and
+              bit-pinned by the parity tests: the first two derive the fp32 score from the integer hit count, the per-hit ones add
+              64-bit fixed-point weights (Q24.40, DESIGN.md section 5.5) -- no float atomics anywhere;
     fast_exp (default True): hardware exp/rcp in render() -- training renders; set False for the canonical,
               bit-pinned arithmetic.  count renders (f_count=True) ALWAYS use the canonical arithmetic;
     profile: record per-kernel hipEvent timings (read with _lib.profile_read());
@@ -370,7 +390,7 @@ def _native_forward(lib, call, rs, count):
             # it knows R and the abort flags before returning (safe drop-in), the device never idled
             host = (C.c_uint32 * 4)()
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                        float(opts["max_depth"]), int(opts["weight_policy"]), _ptr(color), _ptr(radii),
+                                        float(opts["max_depth"]), weight_policy_id(opts["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), None, C.byref(host), stream)
             _lib.check(rc)
             if host[0] == 0:
@@ -388,7 +408,7 @@ def _native_forward(lib, call, rs, count):
             if status is None:
                 status = torch.empty(4, dtype=torch.int32, device=dev)
             rc = lib.lg_forward_bounded(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                        float(opts["max_depth"]), int(opts["weight_policy"]), _ptr(color), _ptr(radii),
+                                        float(opts["max_depth"]), weight_policy_id(opts["weight_policy"]), _ptr(color), _ptr(radii),
                                         _ptr(gcount), _ptr(score), _ptr(status), None, stream)
             _lib.check(rc)
             _note_pending(opts, status, key)
@@ -404,7 +424,7 @@ def _native_forward(lib, call, rs, count):
     R = C.c_int64(0)
     if count:
         rc = lib.lg_forward_count(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None,
-                                  int(opts["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount), _ptr(score),
+                                  weight_policy_id(opts["weight_policy"]), _ptr(color), _ptr(radii), _ptr(gcount), _ptr(score),
                                   C.byref(bin_ptr), C.byref(R), stream)
     else:
         rc = lib.lg_forward(C.byref(call.view), C.byref(call.g), _ptr(geom), _ptr(img), cb, None, _ptr(color), _ptr(radii),

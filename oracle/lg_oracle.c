@@ -325,6 +325,11 @@ void lgo_last_contributor_ids(const lgo_ctx *ctx, const int *n_contrib, uint32_t
 /* per-view score from an integer hit count: c sequential additions of w starting from 0 in
  * the accumulator precision -- exactly what c atomicAdd(score, w) calls produce (all addends
  * equal => order independent).  SURVEY.md section 8a-note. */
+/* Q24.40 restatement of the per-hit weight sums (ALPHA / ALPHA_T policies; see lgo_forward): quantisation of one weight and the
+ * fp32 score of a sum. */
+uint64_t lgo_fix40_quant(float w) { return (uint64_t)llrint(ldexp((double)w, 40)); }
+float lgo_fix40_score(uint64_t q) { return (float)q * 0x1p-40f; }
+
 real lgo_seqsum(real w, int c)
 {
     real s = RC(0.0);
@@ -425,10 +430,15 @@ lgo_ctx *lgo_forward(int N, int M, int D, int W, int H, const real *bg, const re
     free(inst); free(offs); free(touched); free(rects);
 
     if (count) memset(count, 0, (size_t)N * sizeof(int));
-    real *fscore = NULL; /* per-hit float accumulation for ALPHA / ALPHA_T policies */
+    /* ALPHA / ALPHA_T policies: the weight differs from hit to hit, so a float sum would depend on the order of the hits.  The
+     * path's definition: every hit's weight, AS THE fp32 VALUE THE BLEND COMPUTED, is rounded to the nearest
+     * multiple of 2^-40 (ties to even) and the multiples are added as 64-bit integers (Q24.40) -- associative, order-free -- and the
+     * per-view score is that integer rounded once to fp32 (nearest even) times 2^-40.  Independent restatement: llrint(ldexp(w, 40))
+     * under the default rounding mode; the HIP kernel gets the same integer out of the mantissa of (double) w + 4096. */
+    uint64_t *fix = NULL;
     if (score) {
         for (int i = 0; i < N; i++) score[i] = RC(0.0);
-        if (weight_policy == LG_W_ALPHA || weight_policy == LG_W_ALPHA_T) fscore = score;
+        if (weight_policy == LG_W_ALPHA || weight_policy == LG_W_ALPHA_T) fix = (uint64_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(uint64_t));
     }
 
     /* K6 / K6c: per-tile front-to-back blend */
@@ -464,10 +474,11 @@ lgo_ctx *lgo_forward(int N, int M, int D, int W, int H, const real *bg, const re
 #pragma omp atomic
                         count[g] += 1;
                     }
-                    if (fscore) {
-                        const real wv = (weight_policy == LG_W_ALPHA) ? alpha : w;
+                    if (fix) {
+                        const float wv = (float)((weight_policy == LG_W_ALPHA) ? alpha : w);
+                        const uint64_t q = lgo_fix40_quant(wv);
 #pragma omp atomic
-                        fscore[g] += wv;
+                        fix[g] += q;
                     }
                     T = test_T;
                     last = contributor;
@@ -484,6 +495,10 @@ lgo_ctx *lgo_forward(int N, int M, int D, int W, int H, const real *bg, const re
 #pragma omp parallel for schedule(dynamic, 1024)
         for (int i = 0; i < N; i++)
             score[i] = lgo_seqsum(weight_policy == LG_W_ONE ? RC(1.0) : opacities[i], count[i]);
+    }
+    if (fix) {
+        for (int i = 0; i < N; i++) score[i] = (real)lgo_fix40_score(fix[i]);
+        free(fix);
     }
     return ctx;
 }

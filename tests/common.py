@@ -53,6 +53,8 @@ def harness():
     lib = C.CDLL(so)
     lib.h_exp.restype = C.c_float; lib.h_exp.argtypes = [C.c_float]
     lib.h_seqsum32.restype = C.c_float; lib.h_seqsum32.argtypes = [C.c_float, C.c_uint32]
+    lib.h_fix40_quant.restype = C.c_uint64; lib.h_fix40_quant.argtypes = [C.c_float]
+    lib.h_fix40_score.restype = C.c_float; lib.h_fix40_score.argtypes = [C.c_uint64]
     P = C.c_void_p
     lib.h_forward.restype = C.c_int
     lib.h_forward.argtypes = [C.c_int] * 5 + [P] * 6 + [C.c_float] + [P] * 5 + [C.c_float, C.c_float, C.c_int] + [P] * 10

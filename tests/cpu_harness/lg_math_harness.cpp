@@ -13,6 +13,8 @@ extern "C" {
 
 float h_exp(float x) { return lg_exp(x); }
 float h_seqsum32(float w, uint32_t c) { return lg_seqsum32(w, c); }
+uint64_t h_fix40_quant(float w) { return lg_fix40_quant(w); }
+float h_fix40_score(uint64_t q) { return lg_fix40_score(q); }
 
 struct HSplat { LgSplat s; float op, rgb[3], cov[6]; uint32_t clamp; int vis; };
 

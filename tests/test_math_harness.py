@@ -50,6 +50,28 @@ def test_seqsum32_random_weights_and_counts():
         assert _bits(a) == _bits(b), (w, c, a, b)
 
 
+def test_fix40_quantisation_and_score_equal_the_oracle():
+    """The Q24.40 quantisation of a per-hit weight ((double) w + 4096, mantissa bits: lg_math.h) against the oracle's
+    llrint(ldexp(w, 40)), and the u64 -> fp32 score conversion, bit for bit; plus the closed-form properties the design relies on."""
+    lib = common.harness()
+    rs = np.random.RandomState(4)
+    ws = [np.float32(np.exp(rs.uniform(np.log(3.9e-7), np.log(0.99)))) for _ in range(4000)]
+    ws += [np.float32(v) for v in (0.0, 0.99, 1 / 255, 1e-4 / 255, 2.0 ** -17, 2.0 ** -17 - 2.0 ** -41, 2.0 ** -18 + 2.0 ** -41, 3 * 2.0 ** -41,
+                                   2.0 ** -41, 2.0 ** -22 + 2.0 ** -45, 0.5, 0.25 + 2.0 ** -26, 3.9215686e-7)]
+    for w in ws:
+        a, b = lib.h_fix40_quant(float(w)), oracle.fix40_quant(float(w))
+        assert a == b, (w, a, b)
+        if w >= 2.0 ** -17 or w == 0:
+            assert a == int(float(w) * 2 ** 40)          # exactly representable: no quantisation at all
+        assert abs(a - float(w) * 2 ** 40) <= 0.5
+    qs = [int(v) for v in rs.randint(0, 2 ** 62, 2000, dtype=np.int64)] + [0, 1, 2 ** 24 - 1, 2 ** 24 + 1, 2 ** 40, 2 ** 63 + 2 ** 39, 2 ** 64 - 1,
+                                                                         (2 ** 24 + 1) << 16, ((2 ** 24 + 1) << 16) + 1, (2 ** 25 + 3) << 20]
+    for q in qs:
+        a, b = lib.h_fix40_score(q), oracle.fix40_score(q)
+        assert _bits(a) == _bits(b), (q, a, b)
+        assert _bits(a) == _bits(np.float32(np.float32(np.uint64(q)) * np.float32(2.0 ** -40))), q
+
+
 CASES = [dict(N=10000, W=256, H=256, seed=1, scale=0.004, opm=-1.0, ext=(4, 2.25, 4)),
          dict(N=3000, W=200, H=120, seed=2, scale=0.05, opm=1.0, ext=(2, 1.2, 2)),
          dict(N=800, W=128, H=96, seed=3, scale=0.3, opm=2.0, ext=(2, 1, 2)),

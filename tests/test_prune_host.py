@@ -27,11 +27,22 @@ def _scene():
     return g, cams
 
 
-def oracle_count_fn(cam, pc, pipe, bg):
+def oracle_count_fn(cam, pc, pipe, bg, weight_policy=oracle.W_OPACITY):
     """count_render() stand-in running the CPU oracle (test infrastructure)."""
     kw = common.scene_kwargs(pc, cam, cam.image_width, cam.image_height, bg=tuple(bg.tolist()))
-    f = oracle.forward(count=True, **kw)
+    f = oracle.forward(count=True, weight_policy=weight_policy, **kw)
     return {"gaussians_count": torch.from_numpy(f.count.copy()), "important_score": torch.from_numpy(f.score.copy())}
+
+
+def oracle_count_fn_alpha_t(cam, pc, pipe, bg):
+    return oracle_count_fn(cam, pc, pipe, bg, oracle.W_ALPHA_T)
+
+
+def oracle_count_fn_alpha(cam, pc, pipe, bg):
+    return oracle_count_fn(cam, pc, pipe, bg, oracle.W_ALPHA)
+
+
+COUNT_FNS = {"opacity": oracle_count_fn, "alpha": oracle_count_fn_alpha, "alpha_t": oracle_count_fn_alpha_t}
 
 
 def test_prune_list_is_reference_loop_order():
@@ -56,14 +67,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, mode, out_dir, block=24):
+def _worker(rank, world, port, mode, out_dir, block=24, pol="opacity"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g, cams = _scene()
-        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), mode=mode, count_fn=oracle_count_fn, block=block)
+        fn = COUNT_FNS[pol]
+        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), mode=mode, count_fn=fn, block=block, weight_policy=pol)
         if rank == 0:   # local_only inside a distributed job = the single-process loop (what bench.py's mask_equals_1gpu recomputes)
-            c1, i1 = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn, local_only=True, block=3)
+            c1, i1 = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=fn, local_only=True, block=3, weight_policy=pol)
             assert torch.equal(c1, cnt) and (mode != "ordered" or torch.equal(i1, imp))
         v = lg_prune.calculate_v_imp_score(g, imp, 0.1)
         mask = lg_prune.prune_mask(0.66, v)
@@ -90,6 +102,38 @@ def test_sharded_prune_pass_matches_single_process(world, mode, block, tmp_path)
         else:
             assert np.allclose(o["imp"], imp1.numpy(), rtol=1e-5)
             assert np.count_nonzero(o["mask"] != mask1.numpy()) <= 2
+
+
+@pytest.mark.parametrize("pol", ["alpha", "alpha_t"])
+@pytest.mark.parametrize("world,block", [(1, 24), (2, 24), (3, 2)])
+def test_sharded_pass_with_per_hit_weights_is_world_size_independent(world, block, pol, tmp_path):
+    """The per-hit weight policies (Q24.40 fixed-point per-view sums: pure functions of the view) through the same ordered exchange:
+    scores bit-identical to the single-process reference loop and prune-mask Hamming distance 0 at world size 1, 2 and 3."""
+    g, cams = _scene()
+    fn = COUNT_FNS[pol]
+    cnt1, imp1 = lg_prune.prune_list(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=fn)
+    imp_op = lg_prune.prune_list(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=oracle_count_fn)[1]
+    assert not torch.equal(imp1, imp_op)                                    # really another weight
+    mask1 = lg_prune.prune_mask(0.66, lg_prune.calculate_v_imp_score(g, imp1, 0.1))
+    if world == 1:
+        cnt, imp = lg_prune.prune_list_sharded(g, cams, syn.PipelineParams(), torch.zeros(3), count_fn=fn, block=block, weight_policy=pol)
+        assert torch.equal(cnt, cnt1) and torch.equal(imp, imp1)
+        return
+    mp.spawn(_worker, args=(world, _free_port(), "ordered", str(tmp_path), block, pol), nprocs=world, join=True)
+    for r in range(world):
+        o = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(o["cnt"], cnt1.numpy())
+        assert np.array_equal(o["imp"].view(np.uint32), imp1.numpy().view(np.uint32))
+        assert np.array_equal(o["mask"], mask1.numpy())
+
+
+def test_weight_policy_names():
+    from lightgaussian_amd import _lib, rasterizer
+    assert [rasterizer.weight_policy_id(n) for n in ("one", "opacity", "alpha", "ALPHA_T")] == [_lib.WEIGHT_ONE, _lib.WEIGHT_OPACITY, _lib.WEIGHT_ALPHA, _lib.WEIGHT_ALPHA_T]
+    assert rasterizer.weight_policy_id(_lib.WEIGHT_ALPHA) == _lib.WEIGHT_ALPHA
+    for bad in ("alphaT", 4, -1):
+        with pytest.raises(ValueError):
+            rasterizer.weight_policy_id(bad)
 
 
 def test_single_process_pass_in_bounded_chunks_equals_the_reference_loop():
