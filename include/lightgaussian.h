@@ -34,11 +34,14 @@
 extern "C" {
 #endif
 
-/* 6 (round 5): geom buffer layout of round 4 ([N][9] SH direction Jacobian, counters[9]), LG_FLAG_SAVE_SH_JACOBIAN as part of the
+/* 7 (round 6): lg_view.count_sum (running hit count fused into the score kernel); the ALPHA / ALPHA_T weight policies are exact
+ *    64-bit fixed-point sums (Q24.40; out_score bit-reproducible, out_count / out_score written by lg_score_slots) instead of
+ *    float atomics; images beyond 2^24 pixels are refused for them.
+ * 6 (round 5): geom buffer layout of round 4 ([N][9] SH direction Jacobian, counters[9]), LG_FLAG_SAVE_SH_JACOBIAN as part of the
  *    forward / backward contract, lg_debug_* moved to lightgaussian_debug.h (all three shipped under 5 -- ADVICE r4), plus this
  *    round's additions: lg_backward's rgb_only mode, lg_sh_grad_from_rgb, LG_FLAG_BWD_SPLAT_PARALLEL.
  * 5 (round 3): stateless library -- segment length and long-tile mode travel in lg_view. */
-#define LG_ABI_VERSION 6
+#define LG_ABI_VERSION 7
 
 enum {
     LG_OK = 0,
@@ -115,6 +118,11 @@ typedef struct lg_view {
                                 multiple of 64 (small values exist for tests).  The SAME lg_view must be handed to lg_forward* and
                                 to the lg_backward of that view, and to lg_binning_bytes: the forward records the value in the
                                 binning buffer and a backward called with another one writes zero gradients (LG_FLAG_DEBUG: error). */
+    int32_t* count_sum;      /* lg_forward_count / lg_forward_bounded with count outputs, optional (NULL: off): a running per-Gaussian hit
+                                count [N] int32 to which this view's out_count is ADDED by the kernel that writes out_score -- the
+                                `gaussian_list += gaussians_count` of prune_list (prune.py:144-155) without a launch of its own.  Plain
+                                read-modify-write, not atomic: one view at a time per accumulator (views in flight on several streams
+                                use one accumulator per stream).  Ignored by lg_forward and lg_backward. */
 } lg_view;
 
 /* the 8 tensor kwargs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:106-115); means2D is gradient-only */

@@ -25,7 +25,7 @@ FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 FLAG_SAVE_SH_JACOBIAN = 2048
 FLAG_BWD_SPLAT_PARALLEL = 4096
 FLAG_COUNT_WIDE_BAND = 8192
-ABI_VERSION = 6     # include/lightgaussian.h LG_ABI_VERSION this binding was written against (load() refuses another)
+ABI_VERSION = 7     # include/lightgaussian.h LG_ABI_VERSION this binding was written against (load() refuses another)
 
 EXPORTS = ["lg_geom_bytes", "lg_img_bytes", "lg_binning_bytes", "lg_backward_scratch_bytes", "lg_forward",
            "lg_forward_count", "lg_backward", "lg_score_from_count", "lg_abi_version", "lg_last_error",
@@ -42,7 +42,7 @@ class lg_view(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("bg", C.c_void_p), ("scale_modifier", C.c_float), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("sh_degree", C.c_int32), ("campos", C.c_void_p),
-                ("prefiltered", C.c_int32), ("flags", C.c_uint32), ("segment_length", C.c_int32)]
+                ("prefiltered", C.c_int32), ("flags", C.c_uint32), ("segment_length", C.c_int32), ("count_sum", C.c_void_p)]
 
 
 class lg_gaussians(C.Structure):

@@ -391,9 +391,9 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (count && N > 0) {
         ProfScope ps(prof, "score", stream);
         if (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)
-            lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score);
+            lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score, v->count_sum);
         else
-            lg_score_slots<<<(N + 255) / 256, 256, 0, stream>>>(N, geo.touched, geo.tinfo, (const unsigned long long*)bin.keys_in, (uint32_t)cap, out_count, out_score);
+            lg_score_slots<<<(N + 255) / 256, 256, 0, stream>>>(N, geo.touched, geo.tinfo, (const unsigned long long*)bin.keys_in, (uint32_t)cap, out_count, out_score, v->count_sum);
         KCHECK("lg_score_kernel");
     }
     if (debug && N > 0) {
@@ -582,7 +582,7 @@ extern "C" int lg_score_from_count(int32_t N, const int32_t* count, const float*
     if (N < 0 || (N > 0 && (!count || !score))) return fail(LG_ERR_INVALID_ARGUMENT, "bad arguments");
     if (N == 0) return LG_OK;
     hipStream_t stream = (hipStream_t)stream_p;
-    lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score);
+    lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, count, weight, score, nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LG_ERR_DEVICE, "lg_score_kernel launch", e);
     return LG_OK;

@@ -907,22 +907,28 @@ lg_count_fixup(int W, int H, int gx, int S, const uint2* __restrict__ par_work, 
 //  lg_blend_fwd<COUNT, EXACT> on the uniform scene (the count kernel is not bound by the exp polynomial: without its atomics it takes 287 us,
 //  the colour forward with v_exp 260), 941 + 858 us against 846 on the heavy-tailed scene, where 451 pixels per view had to be resolved one
 //  after the other by the waves that own them.  Removed.)
-// per-view score from the exact integer count (ONE / OPACITY weights)
+// per-view score from the exact integer count (ONE / OPACITY weights): score = lg_seqsum32(weight, count), the float that `count`
+// sequential additions of the weight leave (lg_math.h).
+// (Round 6, measured and rejected -- EXPERIMENTS.md: each workgroup compacting its 256 Gaussians to the hit ones, large counts first, so
+//  that full waves of similar walk length run: 0.040 -> 0.039 ms; the same with 2048 persistent workgroups striding over the chunks: 0.045.
+//  The pass rate did not move with either (1715 .. 1731 views/s, box noise).)
 __global__ void __launch_bounds__(256)
-lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score)
+lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score, int32_t* __restrict__ count_sum)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int c = count[i];
     score[i] = c > 0 ? lg_seqsum32(weight ? weight[i] : 1.0f, (uint32_t)c) : 0.0f;
+    if (count_sum && c) count_sum[i] += c;       // lg_view.count_sum: the caller's running hit count (one view at a time per accumulator)
 }
+
 // per-view count and score of the ALPHA / ALPHA_T policies: every Gaussian sums the {count : 16 | Q8.40 : 48} words of its own instances
 // (consecutive pre-sort slots, tinfo.w .. + touched) -- integer adds, any order -- and rounds the Q24.40 total to fp32 ONCE (nearest even),
 // times 2^-40 (exact).  A lane walks up to LG_SLOT_SOLO slots itself; Gaussians with more (screen-filling splats) are summed by the whole wave.
 #define LG_SLOT_SOLO 16u
 __global__ void __launch_bounds__(256)
 lg_score_slots(int N, const uint32_t* __restrict__ touched, const uint4* __restrict__ tinfo, const unsigned long long* __restrict__ slots,
-               uint32_t slot_cap, int32_t* __restrict__ count, float* __restrict__ score)
+               uint32_t slot_cap, int32_t* __restrict__ count, float* __restrict__ score, int32_t* __restrict__ count_sum)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -943,7 +949,10 @@ lg_score_slots(int N, const uint32_t* __restrict__ touched, const uint4* __restr
         for (int sft = 32; sft > 0; sft >>= 1) { c += __shfl_xor(c, sft, 64); f += __shfl_xor(f, sft, 64); }
         if ((int)lane == src) { cnt = c; fix = f; }
     }
-    if (i < N) { count[i] = (int32_t)cnt; score[i] = lg_fix40_score(fix); }
+    if (i < N) {
+        count[i] = (int32_t)cnt; score[i] = lg_fix40_score(fix);
+        if (count_sum && cnt) count_sum[i] += (int32_t)cnt;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

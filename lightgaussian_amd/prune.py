@@ -207,9 +207,17 @@ class _ViewRunner:
         self.streams = max(1, int(streams)) if self.dev.type == "cuda" else 1
         self.host_threads = host_threads
         self.partial = [torch.zeros(N, dtype=torch.int32, device=self.dev) for _ in range(self.streams)]
+        self.fused = count_fn is count_render and self.dev.type == "cuda"      # (test stand-ins for count_fn return their own tensors)
         self.pool = [torch.cuda.Stream(device=self.dev) for _ in range(self.streams)] if self.streams > 1 else []
 
     def _one(self, view, w, rows, k):
+        if self.fused:
+            # the forward writes the score straight into the caller's row and adds the hit count to this stream's running sum inside
+            # its own score kernel (rasterizer options score_out / count_sum): no `+=` and no row copy launched per view
+            from . import rasterizer
+            with rasterizer.options(score_out=rows[k, :self.N], count_sum=self.partial[w]):
+                self.count_fn(view, self.g, self.pipe, self.bg)
+            return
         pkg = self.count_fn(view, self.g, self.pipe, self.bg)
         self.partial[w] += pkg["gaussians_count"].detach().to(torch.int32)
         rows[k, :self.N] = pkg["important_score"].detach()

@@ -47,7 +47,7 @@ _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": F
             "segment_length": 0, "long_tiles": "auto",
             # cross-check switches of the tests: never needed in production, never read from the environment
             "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False, "count_wide_band": False}
-_PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink")
+_PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink", "score_out", "count_sum")
 _LONG_TILES = ("serial", "auto", "parallel")
 _tls = threading.local()
 
@@ -109,6 +109,11 @@ def set_option(name, value):
               with SH inputs then writes dL/d(rgb) per Gaussian (12 B) INSTEAD of the SH-coefficient gradients (12 M B), hands it
               to the sink right behind K9 on the current stream, and returns None for the coefficient gradients: the caller
               rebuilds them for all ranks' views at once (parallel.RankOneSHExchange; the data-parallel step of lightgaussian_amd.dp);
+    score_out, count_sum (per call / per thread only; count forwards): score_out = a contiguous float32 [N] device tensor (e.g. a row of
+              the caller's score matrix) that the forward writes important_score INTO -- the returned important_score is that tensor;
+              count_sum = a contiguous int32 [N] device tensor to which the view's gaussians_count is ADDED by the kernel that writes the
+              score (lg_view.count_sum; not atomic: one view at a time per accumulator).  Together they are prune_list's
+              `gaussian_list += ...; imp_list += ...` bookkeeping (prune.py:144-155) without a torch launch per view (prune_list_sharded);
     bwd_splat_parallel: the backward blend on the other parallel axis (round-5 prototype lg_blend_bwd_splat, DESIGN 22.1);
     count_wide_band: tests only -- LG_FLAG_COUNT_WIDE_BAND (the parallel long-tile count walk sends many more pixels through its exact fix-up);
     sh_jacobian / narrow_key / sort_all_bits / k1_lds: cross-check switches for the tests (K9 re-reads the SH coefficients instead
@@ -378,7 +383,18 @@ def _native_forward(lib, call, rs, count):
     color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((N,), dtype=torch.int32, device=dev)
     gcount = torch.empty((N,), dtype=torch.int32, device=dev) if count else None
-    score = torch.empty((N,), dtype=torch.float32, device=dev) if count else None
+    score = None
+    if count:
+        score = opts.get("score_out")
+        if score is None:
+            score = torch.empty((N,), dtype=torch.float32, device=dev)
+        elif not (torch.is_tensor(score) and score.dtype == torch.float32 and score.device == dev and score.shape == (N,) and score.is_contiguous()):
+            raise ValueError("score_out must be a contiguous float32 [N] tensor on the Gaussians' device")
+        csum = opts.get("count_sum")
+        if csum is not None:
+            if not (torch.is_tensor(csum) and csum.dtype == torch.int32 and csum.device == dev and csum.shape == (N,) and csum.is_contiguous()):
+                raise ValueError("count_sum must be a contiguous int32 [N] tensor on the Gaussians' device")
+            call.view.count_sum = csum.data_ptr() if N > 0 else None
     key = (dev.index, N, W, H)
     mode = opts["sync_free"]
     S = int(opts["segment_length"])

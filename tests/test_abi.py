@@ -40,7 +40,7 @@ def test_library_built_loads_and_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/lightgaussian.h but not exported"
     lib.lg_abi_version.restype = C.c_int
-    assert lib.lg_abi_version() == 6
+    assert lib.lg_abi_version() == 7
     lib.lg_img_bytes.restype = C.c_size_t
     lib.lg_img_bytes.argtypes = [C.c_int32, C.c_int32]
     assert lib.lg_img_bytes(1920, 1080) >= 1920 * 1080 * 8
@@ -96,7 +96,7 @@ def test_the_library_has_no_process_wide_setters_and_the_segment_length_travels_
     for name in ("lg_set_segment_length", "lg_set_long_tile_mode"):
         with pytest.raises(AttributeError):
             getattr(C.CDLL(_lib.LIB_PATH), name)
-    assert [f[0] for f in _lib.lg_view._fields_][-1] == "segment_length"
+    assert [f[0] for f in _lib.lg_view._fields_][-2:] == ["segment_length", "count_sum"]
     for n in (0, 1, 63, 64, 100000):                                     # visibility bytes live inside the geom buffer (host-only query)
         off = lib.lg_geom_visible_offset(n)
         assert off % 16 == 0 and off + n <= lib.lg_geom_bytes(n)
