@@ -917,63 +917,6 @@ def main():
                                             "sync-free forward (gradient accumulation semantics): the VALU-bound blend of one view overlaps the "
                                             "memory-bound stages of another; host_threads_variant = round 1's thread-per-stream scheme"}
 
-    # ---- the step as ONE HIP graph (graph.GraphedStep): same work as `value`, one hipGraphLaunch per step; and a small scene
-    #      (300 k Gaussians, 960 x 540), where the eager step is launch-bound
-    def graph_leg():
-        from lightgaussian_amd.graph import GraphedStep
-
-        def graph_rate(model, cam_of, target_of, keys, nsteps):
-            gstep = GraphedStep(model, pipe, bg, loss=args.loss, lambda_dssim=0.2)
-            for i in range(3):
-                gstep(cam_of[keys[i % len(keys)]], target_of[keys[i % len(keys)]])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(nsteps):
-                k = keys[i % len(keys)]
-                gstep(cam_of[k], target_of[k])
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / nsteps, gstep
-
-        def eager_rate(model, cam_of, target_of, keys, nsteps):
-            ps = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
-            def one(i):
-                k = keys[i % len(keys)]
-                for q in ps:
-                    q.grad = None
-                photometric(render(cam_of[k], model, pipe, bg)["render"], target_of[k]).backward()
-            for i in range(3):
-                one(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(nsteps):
-                one(i)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / nsteps
-
-        keys = list(gts.keys())
-        dt, gs = graph_rate(pc, cams, gts, keys, 60)
-        small = syn.make_gaussians(300_000, sh_degree=args.sh_degree, log_scale_mean=math.log(0.012)).to(dev).requires_grad_(True)
-        scams = {k: syn.orbit_camera(k, 16, 960, 540).to(dev) for k in range(16)}
-        stg = {k: torch.rand(3, 540, 960, device=dev) for k in range(16)}
-        dte = eager_rate(small, scams, stg, list(range(16)), 200)
-        dtg, gs2 = graph_rate(small, scams, stg, list(range(16)), 200)
-        for p in params:
-            p.grad = None
-        result["graph_replay"] = {"views_per_s_per_gpu": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 4), "captures": gs.captures, "repairs": gs.repairs,
-                                  "small_scene_300k_960x540": {"eager_views_per_s": round(1.0 / dte, 1), "graph_views_per_s": round(1.0 / dtg, 1),
-                                                               "captures": gs2.captures, "repairs": gs2.repairs},
-                                  "note": "graph.GraphedStep: render + loss + backward captured once into a HIP graph and replayed with the camera / "
-                                          "target overwritten in place; K2 of every replay writes its status words to pinned host memory and the host polls them while the rest of the replay runs (overflow -> eager repair + re-capture)"}
-        del small, gs, gs2
-
-    # (single-process runs only: a graph capture next to a live RCCL process group's watchdog thread is not worth risking the
-    #  scaling runs for; any failure of this optional leg is reported, not raised)
-    if rank == 0 and world == 1 and args.mode == "fwdbwd" and args.views_in_flight == 1 and not args.no_literal and args.loss in ("l1", "l1_dssim"):
-        try:
-            graph_leg()
-        except Exception as exc:  # noqa: BLE001
-            result["graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-
     # ---- heavier workloads beside the headline (r1 verdict: R/N = 1.38 of the frozen scene is light next to real captures) ----
     if rank == 0 and args.mode == "fwdbwd" and not args.no_literal and args.scene == "uniform" and abs(args.scale - 0.004) < 1e-12:
         def scene_rate(gc, nsteps=60):

@@ -186,8 +186,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             HIP_TRY(lg_zero_async(bin.ranges, (size_t)ntiles * 8, stream));
         }
     }
-    // validated bounded forward: K2 writes its four status words STRAIGHT into pinned host memory (system-scope release on word 0,
-    // as it does for graph.GraphedStep) and the host waits for word 0 to leave its sentinel once everything of the view has been
+    // validated bounded forward: K2 writes its four status words STRAIGHT into pinned host memory (system-scope release on word 0)
+    // and the host waits for word 0 to leave its sentinel once everything of the view has been
     // enqueued -- no device-to-host copy node behind K2 (a 4 us blit kernel + its launch gap on the critical path of every view)
     PinnedSlot vslot;
     const bool host_words = bounded && bounded->host_status;

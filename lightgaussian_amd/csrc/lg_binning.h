@@ -107,7 +107,7 @@ lg_scan_blocks(int nblk, const uint32_t* __restrict__ blk_sum, const uint32_t* _
         counters[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
         if (status) {
             // the caller's copy of the four words (lg_forward_bounded).  `status` may be pinned HOST memory that the host polls
-            // while the rest of the view runs (graph.GraphedStep: word 0 is its "arrived" flag) -- words 1..3 first, then word 0,
+            // while the rest of the view runs (word 0 is the "arrived" flag) -- words 1..3 first, then word 0,
             // each made visible system-wide
             status[1] = f; status[2] = m; status[3] = overflow ? 0xFFFFFFFFu : (uint32_t)carry;
             __threadfence_system();

@@ -41,7 +41,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # Knobs that are not part of the reference API.  _OPTIONS holds the PROCESS DEFAULTS (set_option); every forward takes a
 # snapshot -- defaults, then the calling thread's `with options(...)` blocks, then the call's own `options=` argument -- and the
 # snapshot travels with the call (lg_view.flags / lg_view.segment_length) and into its backward.  Library code never mutates
-# the defaults: prune_list_sharded, backward_over_views, GraphedStep pass what they need per call / per thread.
+# the defaults: prune_list_sharded and backward_over_views pass what they need per call / per thread.
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
             "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
             "segment_length": 0, "long_tiles": "auto",
@@ -419,7 +419,7 @@ def _native_forward(lib, call, rs, count):
                     _CAPACITY[key] = int(int(host[3]) * opts["capacity_margin"]) + 4096
             del binning
         else:
-            # (graph.GraphedStep hands in pinned host words that it polls: the kernels write them directly)
+            # (status_override: a caller-owned [4] int32 tensor that receives the status words)
             status = opts.get("status_override")
             if status is None:
                 status = torch.empty(4, dtype=torch.int32, device=dev)
