@@ -99,6 +99,7 @@ def parse():
     ap.add_argument("--segment-length", type=int, default=0, help="rasterizer option segment_length (0 = library default 512): per-tile lists longer than this "
                     "are cut into independent (tile, segment) work items of the backward")
     ap.add_argument("--long-tiles", choices=["serial", "auto", "parallel"], default="auto", help="rasterizer option long_tiles (walk of outlier tile lists in the forward)")
+    ap.add_argument("--count-long-tiles", choices=["serial", "parallel"], default="serial", help="rasterizer option count_long_tiles (the same for the significance-only count pass)")
     ap.add_argument("--bwd-splat-parallel", action="store_true", help="rasterizer option bwd_splat_parallel: the round-5 PROTOTYPE of the backward blend on the other "
                     "parallel axis (lg_blend_bwd_splat: lane = list entry, pixel state marching through the wave); measurement only, DESIGN 22.1")
     ap.add_argument("--spatial-order", action="store_true", help="NOT the frozen workload: the same Gaussians permuted into Morton order of their "
@@ -305,6 +306,7 @@ def main():
     rasterizer.set_option("fast_exp", not args.exact_exp)
     rasterizer.set_option("segment_length", args.segment_length)
     rasterizer.set_option("long_tiles", args.long_tiles)
+    rasterizer.set_option("count_long_tiles", args.count_long_tiles)
     rasterizer.set_option("bwd_splat_parallel", bool(args.bwd_splat_parallel))
     if args.sync_free != "default":
         rasterizer.set_option("sync_free", False if args.sync_free == "off" else "validated")

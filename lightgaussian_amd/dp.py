@@ -32,8 +32,10 @@ Nothing in the trainers is edited; the glue hangs on four methods of the referen
 Consistency rule: every rank must execute the same collectives in the same order with the same N.  The parameters start equal
 (same checkpoint / point cloud, same seeds: utils/general_utils.py:147-151), receive the same averaged gradients, and every
 pruning / densification decision is a deterministic function of all-reduced data, so they stay equal; `assert_same_count()`
-verifies it (one 8-byte all-gather) wherever N can change.  A mismatch raises on every rank instead of hanging in the next
-collective.  Output files: ranks other than 0 write under <model_path>/.rank<r> (run.py rewrites their -m argument).
+verifies it wherever N can change -- the count AND a 64-bit digest of the positions (one 16-byte all-gather): replicas that drifted
+apart in VALUE with N intact (e.g. a rank whose RNG stream is off by one draw in the reference's densify_and_split,
+scene/gaussian_model.py:666-700 `torch.normal`) would otherwise train `world` silently different models.  A mismatch raises on every
+rank instead of hanging in the next collective.  Output files: ranks other than 0 write under <model_path>/.rank<r> (run.py rewrites their -m argument).
 """
 import os
 import threading
@@ -44,7 +46,7 @@ import torch.distributed as dist
 from . import parallel
 
 _STATE = {"installed": [], "group": None, "visible": {}, "lock": threading.Lock(), "steps": 0, "rows": 0, "dense_steps": 0,
-          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0, "mask_prev": None, "overlap": None}
+          "sinks": {}, "sh_steps": 0, "wire_bytes": 0, "sh_wire_bytes": 0, "mask_prev": None, "overlap": None, "stepped": {}}
 # optimizer group name (scene/gaussian_model.py:204-211) -> attribute the fused rasterizer reports its gradient under
 _GROUP_OF = {"_xyz": "xyz", "_features_dc": "f_dc", "_features_rest": "f_rest", "_opacity": "opacity", "_scaling": "scaling", "_rotation": "rotation"}
 
@@ -102,19 +104,38 @@ def _rank_world():
     return dist.get_rank(_STATE["group"]), dist.get_world_size(_STATE["group"])
 
 
-def assert_same_count(n, what="Gaussians"):
-    """Every rank must hold the same number of Gaussians before a collective sized by it.  One int64 all-gather."""
+def replica_digest(t):
+    """64-bit digest of a replicated tensor's VALUES: the int64 sum of its 32-bit patterns (one reduction kernel, no host copy of the
+    tensor).  Equal replicas give equal digests; one differing element changes it unless another difference cancels it exactly."""
+    if t is None or t.numel() == 0:
+        return torch.zeros((), dtype=torch.int64, device=t.device if t is not None else "cpu")
+    return torch.sum(t.detach().contiguous().view(torch.int32), dtype=torch.int64)
+
+
+def assert_same_count(n, what="Gaussians", values=None):
+    """Every rank must hold the same Gaussians before a collective sized by them: the same NUMBER and -- `values` (the model's _xyz)
+    given -- the same VALUES (replica_digest).  One all-gather of two int64 per rank; a mismatch raises on every rank."""
     if not active():
         return
     rank, world = _rank_world()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(_STATE["group"]) == "nccl" else torch.device("cpu")
-    mine = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+    mine = torch.zeros(2, dtype=torch.int64, device=dev)
+    mine[0] = int(n)
+    if values is not None:
+        mine[1] = replica_digest(values).to(dev)
     allc = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allc, mine, group=_STATE["group"])
-    counts = [int(t.item()) for t in allc]
+    rows = [t.tolist() for t in allc]
+    counts = [int(r[0]) for r in rows]
     if len(set(counts)) != 1:
         raise RuntimeError(f"data-parallel ranks diverged: number of {what} per rank = {counts} (rank {rank}); the next collective would "
                            "mismatch.  Every rank must load the same model and take the same prune / densify decisions.")
+    digests = [int(r[1]) for r in rows]
+    if len(set(digests)) != 1:
+        raise RuntimeError(f"data-parallel ranks diverged in VALUE: the {what} hold different positions on different ranks (digest per rank = "
+                           f"{[hex(d & 0xFFFFFFFFFFFFFFFF) for d in digests]}, rank {rank}) although their number agrees.  The replicas no longer "
+                           "train one model -- typically a random-number stream that is out of step between the ranks (the reference's "
+                           "densify_and_split draws from torch.normal): seed every rank identically and draw nothing rank-dependent.")
 
 
 # ---- visibility of the step's renders -------------------------------------------------------------------------------------------
@@ -173,6 +194,11 @@ def _sink_for(pc, override_color, pipe):
     if not isinstance(getattr(pc, "_features_dc", None), torch.Tensor) or not isinstance(getattr(pc, "_features_rest", None), torch.Tensor):
         return None
     with _STATE["lock"]:
+        # only models whose optimizer.step is the wrapped one get a sink: anywhere else (an optimizer created before install(), a teacher with
+        # requires_grad) nobody would rebuild the SH gradients from it and f_dc / f_rest would silently stop training
+        reg = _STATE["stepped"].get(id(xyz))
+        if reg is None or reg() is not xyz:
+            return None
         ent = _STATE["sinks"].get(id(xyz))
         if ent is None or ent[0] is not xyz:
             ent = _STATE["sinks"][id(xyz)] = (xyz, parallel.RankOneSHExchange(_STATE["group"], average=True, force=_forced()))
@@ -206,9 +232,9 @@ def _check_same_set(mask_bits, force=False):
         return
     group = _STATE["group"]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    t = torch.tensor([mask_bits, (~mask_bits) & 0xFFFF], dtype=torch.int64, device=dev)
+    t = torch.tensor([mask_bits, (~mask_bits) & 0xFFFFFFFF], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    hi, lo = int(t[0].item()), (~int(t[1].item())) & 0xFFFF
+    hi, lo = int(t[0].item()), (~int(t[1].item())) & 0xFFFFFFFF
     if hi != mask_bits or lo != mask_bits:
         raise RuntimeError(f"data-parallel step: the ranks hold gradients for different parameter groups (this rank: mask {mask_bits:#x}, union "
                            f"{hi:#x}, intersection {lo:#x}); every rank must differentiate the same set of parameters")
@@ -249,66 +275,78 @@ def exchange_gradients(optimizer, check=None, force=None):
     if sink is not None and (sh_params[0] is None or sh_params[1] is None or by_name.get("xyz") is None):
         raise RuntimeError("data-parallel step: dRGB was collected for a model whose optimizer has no f_dc / f_rest / xyz groups "
                            "(scene/gaussian_model.py:204-211 names them); use dp.configure(sh='dense')")
-    have = [p for p in params if p.grad is not None and not any(p is q for q in sh_params)]
+    # An SH group that ALREADY holds a gradient next to the sink's dRGB -- another render of the step went through override_color /
+    # convert_SHs_python / a render() without `options`, or a regulariser acts on the coefficients: that gradient is all-reduced like the
+    # other tensors and the rebuilt one is ADDED to it (it used to be overwritten, and was never reduced).
+    have = [p for p in params if p.grad is not None]
     _STATE["steps"] += 1
     mask_bits = sum(1 << i for i, p in enumerate(params[:16]) if p.grad is not None or any(p is q for q in sh_params))
+    mask_bits |= sum(1 << (16 + i) for i, p in enumerate(params[:16]) if p.grad is not None and any(p is q for q in sh_params))
     _check_same_set(mask_bits, force)
     vis = _take_visible(params)
     if not have and sink is None:
         return None
-    info = {"mode": "dense", "of": int(params[0].shape[0]), "params": len(have) + len(sh_params)}
+    info = {"mode": "dense", "of": int(params[0].shape[0]), "params": len(have) + sum(1 for q in sh_params if q.grad is None)}
+    rebuilt = []
     if sink is not None:
         xyz = by_name["xyz"]
         M = 1 + int(sh_params[1].shape[1])
         g_dc, g_rest = sink.finish(xyz, M)
-        sh_params[0].grad = g_dc.view_as(sh_params[0])
-        sh_params[1].grad = g_rest.view_as(sh_params[1])
+        rebuilt = [(sh_params[0], g_dc.view_as(sh_params[0])), (sh_params[1], g_rest.view_as(sh_params[1]))]
         _STATE["sh_steps"] += 1
         _STATE["wire_bytes"] += sink.bytes_on_wire
         _STATE["sh_wire_bytes"] += sink.bytes_on_wire
         info.update(mode="rank1_sh+dense", sh_bytes_on_wire=sink.bytes_on_wire)
-    ov = _STATE.get("overlap")
-    if ov is not None and ov.grads is not None:
-        # install(overlap=True) / run.py --dp-overlap: the step's ONE rasterizer backward ran its per-Gaussian stage in ranges, and each range of the
-        # (non-SH) gradient tensors was all-reduced on a side stream while K9 computed the next one (parallel.OverlappedGradAllReduce over
-        # lg_backward_chunked).  The reduced tensors replace what autograd put into the leaves; whatever the hook did not see -- the literal
-        # getter pattern reports gradients of the ACTIVATED tensors, which are not parameters -- goes through the dense all-reduce below.
-        reduced = ov.finish(None)
-        ov.grads = None
-        done = []
-        if all(n in _GROUP_OF for n in reduced):
-            for n, g in reduced.items():
-                q = by_name.get(_GROUP_OF[n])
-                if q is not None and q.grad is not None and q.grad.numel() == g.numel():
-                    q.grad = g.view_as(q)
-                    done.append(q)
-        have = [q for q in have if not any(q is d for d in done)]
-        info["overlapped"] = len(done)
-        _STATE["overlap_steps"] = _STATE.get("overlap_steps", 0) + (1 if done else 0)
-    if not have:
-        return info
-    N = have[0].shape[0]
-    rows_ok = sink is None and vis is not None and vis.shape[0] == N and all(p.grad.shape[0] == N for p in have) and len(have) == len(params)
-    if rows_ok and not _CONFIG["dense"]:
-        if check is None:
-            check = _CONFIG["check"] is True or (_CONFIG["check"] is None and _STATE["steps"] % 64 == 1)
-        if check:
-            hidden = ~vis.reshape(-1).bool()
-            for p in have:
-                if bool((p.grad.reshape(N, -1)[hidden] != 0).any()):
-                    raise RuntimeError("data-parallel step: a gradient row of a Gaussian no render of this step saw is non-zero; the "
-                                       "visible-rows exchange would leave it unreduced (use dp.configure(dense=True))")
-        k, _ = parallel.allreduce_gradients_visible(have, vis, group=_STATE["group"], force=force)
-        _STATE["rows"] += k
+
+    def _rest(have):
+        nonlocal check
+        ov = _STATE.get("overlap")
+        if ov is not None and ov.grads is not None:
+            # install(overlap=True) / run.py --dp-overlap: the step's ONE rasterizer backward ran its per-Gaussian stage in ranges, and each range of the
+            # (non-SH) gradient tensors was all-reduced on a side stream while K9 computed the next one (parallel.OverlappedGradAllReduce over
+            # lg_backward_chunked).  The reduced tensors replace what autograd put into the leaves; whatever the hook did not see -- the literal
+            # getter pattern reports gradients of the ACTIVATED tensors, which are not parameters -- goes through the dense all-reduce below.
+            reduced = ov.finish(None)
+            ov.grads = None
+            done = []
+            if all(n in _GROUP_OF for n in reduced):
+                for n, g in reduced.items():
+                    q = by_name.get(_GROUP_OF[n])
+                    if q is not None and q.grad is not None and q.grad.numel() == g.numel():
+                        q.grad = g.view_as(q)
+                        done.append(q)
+            have = [q for q in have if not any(q is d for d in done)]
+            info["overlapped"] = len(done)
+            _STATE["overlap_steps"] = _STATE.get("overlap_steps", 0) + (1 if done else 0)
+        if not have:
+            return info
+        N = have[0].shape[0]
+        rows_ok = sink is None and vis is not None and vis.shape[0] == N and all(p.grad.shape[0] == N for p in have) and len(have) == len(params)
+        if rows_ok and not _CONFIG["dense"]:
+            if check is None:
+                check = _CONFIG["check"] is True or (_CONFIG["check"] is None and _STATE["steps"] % 64 == 1)
+            if check:
+                hidden = ~vis.reshape(-1).bool()
+                for p in have:
+                    if bool((p.grad.reshape(N, -1)[hidden] != 0).any()):
+                        raise RuntimeError("data-parallel step: a gradient row of a Gaussian no render of this step saw is non-zero; the "
+                                           "visible-rows exchange would leave it unreduced (use dp.configure(dense=True))")
+            k, _ = parallel.allreduce_gradients_visible(have, vis, group=_STATE["group"], force=force)
+            _STATE["rows"] += k
+            world = dist.get_world_size(_STATE["group"])
+            _STATE["wire_bytes"] += int(2 * (N + k * sum(p.grad[0].numel() * 4 for p in have)) * (world - 1) / max(world, 1))
+            info.update(mode="visible", rows=k)
+            return info
+        _STATE["dense_steps"] += 1
+        info["collectives"] = parallel.allreduce_gradients(have, group=_STATE["group"], force=force)
+        nb = sum(p.grad.numel() * 4 for p in have)
         world = dist.get_world_size(_STATE["group"])
-        _STATE["wire_bytes"] += int(2 * (N + k * sum(p.grad[0].numel() * 4 for p in have)) * (world - 1) / max(world, 1))
-        info.update(mode="visible", rows=k)
+        _STATE["wire_bytes"] += int(2 * nb * (world - 1) / max(world, 1))
         return info
-    _STATE["dense_steps"] += 1
-    info["collectives"] = parallel.allreduce_gradients(have, group=_STATE["group"], force=force)
-    nb = sum(p.grad.numel() * 4 for p in have)
-    world = dist.get_world_size(_STATE["group"])
-    _STATE["wire_bytes"] += int(2 * nb * (world - 1) / max(world, 1))
+
+    info = _rest(have)
+    for q, g in rebuilt:                       # (after the all-reduce of whatever autograd had put there)
+        q.grad = g if q.grad is None else q.grad.add_(g)
     return info
 
 
@@ -321,18 +359,39 @@ def wrap_optimizer(optimizer):
     def step(*a, **kw):
         # (configure(force=True): exchange at world size 1 too -- the RCCL code path of a 1-GPU box, tests/test_gpu_dp_runner.py)
         exchange_gradients(optimizer)
-        with _STATE["lock"]:
-            # visibility / dRGB recorded for models that are never stepped, or whose _xyz was replaced by a prune / densify between
-            # backward() and step(): do not keep the old tensors alive
-            live = {id(p) for g in optimizer.param_groups for p in g["params"]}
-            for store in (_STATE["visible"], _STATE["sinks"]):
-                for key in [k for k in store if k not in live and len(store) > 4]:
-                    store.pop(key, None)
-        return inner(*a, **kw)
+        out = inner(*a, **kw)
+        _register(optimizer)
+        return out
 
     optimizer.step = step
     optimizer._lg_dp_wrapped = True
+    _register(optimizer)
     return optimizer
+
+
+def _register(optimizer):
+    """Remember which model (by its `xyz` parameter) this wrapped optimizer steps -- only such models are handed an SH-gradient sink -- and
+    drop what was recorded for tensors that are no parameter of it any more: a prune / densify between backward() and step() replaces every
+    Parameter (train_densify_prune.py), and the sink of the old _xyz would otherwise pin it and the gathered [world, 3 N + 3] buffers for the
+    rest of the run (ADVICE r5: 0.3 GB per stale sink at 3 M Gaussians on 8 ranks).  Every stale entry goes, whatever the size of the store;
+    outstanding gathers are waited for first."""
+    import weakref
+    with _STATE["lock"]:
+        live = {id(p): p for g in optimizer.param_groups for p in g["params"]}
+        mine = getattr(optimizer, "_lg_dp_ids", set())
+        for key in [k for k in mine if k not in live]:
+            _STATE["stepped"].pop(key, None)
+            ent = _STATE["sinks"].pop(key, None)
+            if ent is not None:
+                ent[1].abandon()
+            _STATE["visible"].pop(key, None)
+        for key in [k for k, ref in _STATE["stepped"].items() if ref() is None]:
+            _STATE["stepped"].pop(key, None)
+        for g in optimizer.param_groups:
+            if g.get("name") == "xyz":
+                for p in g["params"]:
+                    _STATE["stepped"][id(p)] = weakref.ref(p)
+        optimizer._lg_dp_ids = set(live)
 
 
 # ---- patches on the reference's classes ------------------------------------------------------------------------------------------
@@ -411,11 +470,11 @@ def install(gaussian_model_cls=None, scene_cls=None, group=None, overlap=None, *
 
         def densify_and_prune(self, *a, **kw):
             if active():
-                assert_same_count(self.get_xyz.shape[0])
+                assert_same_count(self.get_xyz.shape[0], values=self.get_xyz)
                 dist.all_reduce(self.max_radii2D, op=dist.ReduceOp.MAX, group=_STATE["group"])
             out = orig_dap(self, *a, **kw)
             if active():
-                assert_same_count(self.get_xyz.shape[0], "Gaussians after densify_and_prune")
+                assert_same_count(self.get_xyz.shape[0], "Gaussians after densify_and_prune", values=self.get_xyz)
             return out
 
         densify_and_prune._lg_dp = True
@@ -433,7 +492,10 @@ def uninstall():
             except AttributeError:
                 pass
     _STATE["visible"].clear()
+    for _k, ent in list(_STATE["sinks"].items()):
+        ent[1].abandon()
     _STATE["sinks"].clear()
+    _STATE["stepped"].clear()
     if _STATE.get("overlap") is not None:
         _STATE["overlap"].__exit__(None, None, None)
         _STATE["overlap"] = None

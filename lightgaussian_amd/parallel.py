@@ -329,18 +329,19 @@ class RankOneSHExchange:
             cur = torch.cuda.current_stream(drgb.device)
             if self.comm is None:
                 self.comm = torch.cuda.Stream(device=drgb.device)
+            # one message per view: the centre rides behind the colours in the same buffer.  Built on the CURRENT stream, before the event:
+            # the side stream then reads nothing but this buffer (`campos` used to be read there without a record_stream)
+            payload = torch.cat((drgb.reshape(-1), campos))
             ev = torch.cuda.Event()
             ev.record(cur)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                # one message per view: the centre rides behind the colours in the same buffer
-                payload = torch.cat((drgb.reshape(-1), campos))
                 gathered = torch.empty((self.world, 3 * N + 3), dtype=drgb.dtype, device=drgb.device)
                 if dist.get_backend(self.group) == "nccl":
                     work = dist.all_gather_into_tensor(gathered, payload, group=self.group, async_op=True)
                 else:           # (gloo on device tensors: the shared-GPU test mode of bench.py)
                     work = dist.all_gather(list(gathered.unbind(0)), payload, group=self.group, async_op=True)
-            drgb.record_stream(self.comm)
+            payload.record_stream(self.comm)
         else:
             payload = torch.cat((drgb.reshape(-1), campos))
             gathered = torch.empty((self.world, 3 * N + 3), dtype=drgb.dtype)
@@ -348,6 +349,20 @@ class RankOneSHExchange:
             work = dist.all_gather(parts, payload, group=self.group, async_op=True)
         self.bytes_on_wire += payload.numel() * 4 * (1 + max(self.world - 1, 0))
         self.views.append((gathered, None, int(sh_degree), work))
+
+    def abandon(self):
+        """Drop the views collected so far (their model was replaced before its step): wait for the outstanding gathers, free the buffers."""
+        for _g, _c, _d, work in self.views:
+            if work is not None:
+                try:
+                    if self.comm is not None:
+                        with torch.cuda.stream(self.comm):
+                            work.wait()
+                    else:
+                        work.wait()
+                except Exception:  # noqa: BLE001 -- a failed collective surfaces in the next one; nothing to rebuild here
+                    pass
+        self.views = []
 
     def finish(self, xyz, M):
         """Wait for the gathers and rebuild the coefficient gradients: returns (g_dc [N,1,3], g_rest [N,M-1,3]); clears the sink."""

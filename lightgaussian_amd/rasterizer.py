@@ -44,7 +44,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # the defaults: prune_list_sharded and backward_over_views pass what they need per call / per thread.
 _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": False, "skip_color_in_count": False,
             "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
-            "segment_length": 0, "long_tiles": "auto",
+            "segment_length": 0, "long_tiles": "auto", "count_long_tiles": "serial",
             # cross-check switches of the tests: never needed in production, never read from the environment
             "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False, "count_wide_band": False}
 _PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink", "score_out", "count_sum")
@@ -71,6 +71,8 @@ def _validate(name, value):
         weight_policy_id(value)
     if name == "long_tiles" and value not in _LONG_TILES:
         raise ValueError(f"long_tiles must be one of {_LONG_TILES}")
+    if name == "count_long_tiles" and value not in ("serial", "parallel"):
+        raise ValueError("count_long_tiles must be 'serial' or 'parallel'")
     if name == "segment_length" and (int(value) < 0 or (int(value) != 0 and (int(value) < 64 or int(value) % 64))):
         raise ValueError("segment_length must be 0 (library default, 512) or a multiple of 64")
 
@@ -105,6 +107,11 @@ def set_option(name, value):
               travels in lg_view.segment_length, the backward of a view uses the value its forward ran with;
     long_tiles: "serial" | "auto" (default) | "parallel": walk of outlier tile lists in training forwards; "auto" is
               decided on the device from the view's own list statistics -- no dependence on earlier views;
+    count_long_tiles: "serial" (default) | "parallel": the same choice for the significance-only count pass (skip_color_in_count, integer
+              weights), which has a parallel long-tile walk of its own (lg_count_seg / _rewalk / _fixup; bit-identical counts).  An option of
+              its own since round 6: the walk measured SLOWER than the serial one with several views in flight (1150 vs 1497 views/s on the
+              heavy-tailed scene), so a process that sets long_tiles="parallel" for its training forwards must not get it for its prune pass
+              as a side effect (ADVICE r5);
     sh_grad_sink (per call / per thread only): an object with .add(drgb [N,3], campos [3], sh_degree) -- the backward of a render
               with SH inputs then writes dL/d(rgb) per Gaussian (12 B) INSTEAD of the SH-coefficient gradients (12 M B), hands it
               to the sink right behind K9 on the current stream, and returns None for the coefficient gradients: the caller
@@ -256,7 +263,10 @@ class _Call:
             flags |= _lib.FLAG_PROFILE
         if exact and opts["skip_color_in_count"]:
             flags |= _lib.FLAG_SKIP_COLOR
-        flags |= {"serial": _lib.FLAG_LONG_SERIAL, "auto": 0, "parallel": _lib.FLAG_LONG_PARALLEL}[opts["long_tiles"]]
+        if exact:       # count forward: its own switch (the training forward's long_tiles does not reach the significance pass)
+            flags |= _lib.FLAG_LONG_PARALLEL if opts["count_long_tiles"] == "parallel" else _lib.FLAG_LONG_SERIAL
+        else:
+            flags |= {"serial": _lib.FLAG_LONG_SERIAL, "auto": 0, "parallel": _lib.FLAG_LONG_PARALLEL}[opts["long_tiles"]]
         # cross-check switches (tests pass them as options)
         if opts["narrow_key"]:
             flags |= _lib.FLAG_NARROW_KEY

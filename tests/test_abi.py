@@ -154,7 +154,7 @@ def test_options_are_resolved_per_call_and_per_thread_never_by_mutating_the_defa
 
 def test_prune_pass_and_view_runner_do_not_touch_the_process_defaults():
     import inspect
-    from lightgaussian_amd import prune, parallel, graph
-    for mod in (prune, parallel, graph):
+    from lightgaussian_amd import prune, parallel, dp
+    for mod in (prune, parallel, dp):
         src = inspect.getsource(mod)
         assert "set_option(" not in src and "_OPTIONS[" not in src, mod.__name__

@@ -132,7 +132,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     return {"render": image + 0.0 * points.sum(), "viewspace_points": points, "visibility_filter": vis, "radii": vis.int() * (3 + cam)}
 
 
-def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None):
+def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None, sh_reg=False):
     from random import randint
     stack = None
     for it in range(steps):
@@ -141,7 +141,10 @@ def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None
                 stack = scene.getTrainCameras().copy()
             cam = stack.pop(randint(0, len(stack) - 1))
             pkg = render_fn(cam, model, None, None)
-            (pkg["render"] - 0.25).abs().mean().backward()
+            loss = (pkg["render"] - 0.25).abs().mean()
+            if sh_reg:     # a regulariser on the SH coefficients: autograd puts a gradient on f_dc / f_rest NEXT to the sink's dRGB
+                loss = loss + 1e-2 * (model._features_rest * (1.0 + 0.1 * cam)).pow(2).mean() + 1e-2 * model._features_dc.abs().mean()
+            loss.backward()
         if reset_at == it:
             model.reset_opacity()                          # between backward() and step(), as train_densify_prune.py:194-197
         with torch.no_grad():
@@ -149,7 +152,7 @@ def trainer_loop(model, scene, render_fn, steps, views_per_step=1, reset_at=None
             model.optimizer.zero_grad(set_to_none=True)
 
 
-def _run(mode, views_per_step=1, reset_at=None, overlap=False):
+def _run(mode, views_per_step=1, reset_at=None, overlap=False, sh_reg=False):
     dp.uninstall()                                     # (also puts every switch back to its default)
     # check_set=True: compare the parameter sets on every step (default: first steps, every 64th, on a change)
     dp.install(Model, Scene, overlap=overlap, sh=mode, check=False, check_set=True)
@@ -157,7 +160,7 @@ def _run(mode, views_per_step=1, reset_at=None, overlap=False):
     model, scene = Model(), Scene()
     model.training_setup(None)
     before = dp.stats()
-    trainer_loop(model, scene, dp.wrap_render(render), 3, views_per_step, reset_at)
+    trainer_loop(model, scene, dp.wrap_render(render), 3, views_per_step, reset_at, sh_reg)
     after = dp.stats()
     return model, {k: after[k] - before[k] for k in after}
 
@@ -190,6 +193,37 @@ def _worker(rank, world, port, out_dir):
                 k = kw.get("views_per_step", 1)
                 assert sa["bytes_on_wire"] < 0.5 * sb["bytes_on_wire"]
                 assert sa["sh_bytes_on_wire"] == 3 * k * (3 * N + 3) * 4 * world and sb["sh_bytes_on_wire"] == 0
+        # an SH group that already holds a gradient of its own (a regulariser on the coefficients) when the sink is finished --
+        # that gradient is all-reduced and the rebuilt one ADDED (it used to be overwritten, unreduced): equal to the dense exchange up to
+        # the association of the sum, and the same bits on both ranks (the caller compares the files)
+        a, sa = _run("rank1", sh_reg=True)
+        b, sb = _run("dense", sh_reg=True)
+        assert sa["rank1_sh_steps"] == 3 and sb["rank1_sh_steps"] == 0
+        for n, p, q in zip(NAMES, a._params(), b._params()):
+            assert torch.allclose(p, q, rtol=2e-5, atol=1e-6), f"sh_reg: {n} differs between the rank-one and the dense exchange on rank {rank}"
+        plain, _ = _run("rank1")
+        assert not torch.allclose(a._features_rest, plain._features_rest, rtol=1e-4, atol=1e-6)      # the regulariser did act
+        res["shreg"] = [p.detach().numpy() for p in a._params()]
+        # a model whose optimizer is NOT the wrapped one gets no sink (nobody would rebuild its SH gradients), and what was recorded for
+        # parameters that a prune / densify replaced before the step is dropped at that step, whatever the size of the store
+        dp.uninstall(); dp.install(Model, Scene, sh="rank1", check_set=True)
+        loose = Model()
+        loose.optimizer = torch.optim.Adam([{"params": [p], "lr": 0.01, "name": n} for p, n in zip(loose._params(), NAMES)], lr=0.0, eps=1e-15)
+        assert dp._sink_for(loose, None, None) is None
+        wrapped = Model(); wrapped.training_setup(None)
+        sink = dp._sink_for(wrapped, None, None)
+        assert sink is not None and dp._sink_for(wrapped, None, None) is sink
+        pkg = dp.wrap_render(render)(0, wrapped, None, None)
+        (pkg["render"] - 0.25).abs().mean().backward()
+        assert len(sink.views) == 1 and len(dp._STATE["sinks"]) == 1 and len(dp._STATE["visible"]) == 1
+        old_xyz = wrapped._xyz
+        wrapped._xyz = torch.nn.Parameter(old_xyz.detach().clone())          # prune_points / densification_postfix: every Parameter is new
+        wrapped.optimizer.param_groups[0]["params"][0] = wrapped._xyz
+        for q in wrapped._params():
+            q.grad = torch.zeros_like(q)
+        wrapped.optimizer.step()
+        assert not dp._STATE["sinks"] and not dp._STATE["visible"] and sink.views == [] and id(old_xyz) not in dp._STATE["stepped"]
+        assert dp._sink_for(wrapped, None, None) is not None                   # the new _xyz is the registered one now
         # a group without a gradient on ONE rank only: refused on every rank (the union / intersection of the masks differ from somebody's)
         m = Model(); m.training_setup(None)
         for i, p in enumerate(m._params()):

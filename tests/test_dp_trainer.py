@@ -61,9 +61,11 @@ class Model:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
-    def densify_and_prune(self, drop):
+    def densify_and_prune(self, drop, split=False):
         if drop:
             self._xyz = torch.nn.Parameter(self._xyz[:-drop].detach())
+        if split:     # scene/gaussian_model.py:666-700 densify_and_split in effect: new positions drawn from the process's RNG stream
+            self._xyz = torch.nn.Parameter(torch.cat((self._xyz.detach(), self._xyz.detach()[:7] + torch.normal(torch.zeros(7, 3), 0.01))))
 
 
 class Scene:
@@ -142,6 +144,22 @@ def _worker(rank, world, port, out_dir):
             raised = False
         except RuntimeError as e:
             raised = "diverged" in str(e)
+        assert raised
+        # ... and so must replicas that diverged in VALUE with N intact (r5 verdict): both ranks split the same seven Gaussians, but rank 1's
+        # random-number stream is one draw ahead (utils/general_utils.py:147-151 seeds every rank alike; anything rank-dependent that draws
+        # breaks that silently) -- the positions differ, the count does not
+        m3 = Model(); m3.training_setup(None)
+        torch.manual_seed(123)
+        m3.densify_and_prune(0, split=True)               # same stream on both ranks: passes, N grew by 7 everywhere
+        assert m3.get_xyz.shape[0] == N + 7
+        torch.manual_seed(123)
+        if rank == 1:
+            torch.randn(1)
+        try:
+            m3.densify_and_prune(0, split=True)
+            raised = False
+        except RuntimeError as e:
+            raised = "diverged in VALUE" in str(e)
         assert raised
         # the dense fallback: a step whose renders dp did not see
         m2 = Model(); m2.training_setup(None)

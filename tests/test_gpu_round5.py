@@ -260,15 +260,15 @@ COUNT_SCENES = [dict(N=5000, W=96, H=64, scale=0.12, opm=1.5, seed=17),        #
 @pytest.mark.parametrize("S", [64, 128])
 @pytest.mark.parametrize("sc", COUNT_SCENES, ids=lambda s: f"N{s['N']}_op{s['opm']}")
 def test_parallel_count_walk_gives_the_serial_counts_bit_for_bit(sc, S, wide):
-    """Significance-only pass, every multi-segment list through lg_count_seg / _rewalk / _fixup (long_tiles="parallel"): hit counts and
+    """Significance-only pass, every multi-segment list through lg_count_seg / _rewalk / _fixup (count_long_tiles="parallel"): hit counts and
     scores bit-identical to the serial walk and to the oracle.  wide_band: the comparison band 4096 x wider, so that the exact fix-up
     resolves hundreds of pixels instead of (usually) none -- the counts must not move."""
     g = _scene(N=sc["N"], seed=sc["seed"], scale=sc["scale"], opm=sc["opm"])
     W, H = sc["W"], sc["H"]
     cam = syn.orbit_camera(2, 7, W, H, radius=5.0)
     base = {"segment_length": S}
-    c_ser, s_ser, m_ser, t = _count_pass(g, cam, W, H, dict(base, long_tiles="serial"))
-    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(base, long_tiles="parallel", count_wide_band=wide))
+    c_ser, s_ser, m_ser, t = _count_pass(g, cam, W, H, dict(base, count_long_tiles="serial"))
+    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(base, count_long_tiles="parallel", count_wide_band=wide))
     # (the serial pass launches no work-list workgroup: its meta words are whatever the allocator left there)
     assert m_par[4] > 0 and m_par[2] == S and m_par[1] > 2 * S, m_par[:6]   # the parallel kernels really had items, of lists of several segments
     assert np.array_equal(c_ser, c_par), f"{int((c_ser != c_par).sum())} counts differ, sum {int(c_ser.sum())} vs {int(c_par.sum())}, fix-ups {m_par[5]}"
@@ -283,7 +283,7 @@ def test_parallel_count_walk_gives_the_serial_counts_bit_for_bit(sc, S, wide):
 
 
 def test_parallel_count_walk_on_the_heavy_tailed_scene():
-    """long_tiles="parallel" with the default segment length on a heavy-tailed scene (lists of thousands of entries): counts equal the
+    """count_long_tiles="parallel" with the default segment length on a heavy-tailed scene (lists of thousands of entries): counts equal the
     serial walk's; the default rule keeps the significance pass serial (measured faster with views in flight), and
     count_render -- which returns an image -- always walks serially."""
     from lightgaussian_amd.gaussian_renderer import count_render
@@ -291,8 +291,8 @@ def test_parallel_count_walk_on_the_heavy_tailed_scene():
     syn.make_heavy_tailed(g, frac=0.08)
     W, H = 960, 540
     cam = syn.orbit_camera(0, 10, W, H)
-    c_ser, s_ser, _m, _ = _count_pass(g, cam, W, H, dict(long_tiles="serial"))
-    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(long_tiles="parallel"))
+    c_ser, s_ser, _m, _ = _count_pass(g, cam, W, H, dict(count_long_tiles="serial"))
+    c_par, s_par, m_par, _ = _count_pass(g, cam, W, H, dict(count_long_tiles="parallel"))
     c_def, s_def, _m2, _ = _count_pass(g, cam, W, H, {})
     assert m_par[4] > 0 and m_par[1] > 4 * 512, m_par[:6]
     assert np.array_equal(c_ser, c_par) and np.array_equal(s_ser.view(np.uint32), s_par.view(np.uint32))

@@ -85,7 +85,7 @@ def test_long_lists_and_saturating_piles_keep_the_scores_bit_identical(pol):
     kw = common.scene_kwargs(g, cam, 208, 144, deg=1, bg=(0.0, 0.0, 0.0), as_torch=True)
     ref = oracle.forward(count=True, weight_policy=POLICIES[pol], **_np(kw))
     assert ref.num_rendered / ((208 // 16) * (144 // 16)) > 300
-    for extra in ({}, {"segment_length": 64}, {"segment_length": 64, "long_tiles": "parallel", "skip_color_in_count": True}):
+    for extra in ({}, {"segment_length": 64}, {"segment_length": 64, "count_long_tiles": "parallel", "skip_color_in_count": True}):
         with rasterizer.options(weight_policy=pol, **extra):
             out = gpu_common.hip_forward_backward(kw, count=True)
         assert np.array_equal(out["count"], ref.count), extra

@@ -163,7 +163,7 @@ for t in range(first, first + n3):
     ref = oracle.forward(count=True, **npk)
     why = []
     with torch.no_grad():
-        for tag, opt in (("serial", dict(long_tiles="serial")), ("parallel", dict(long_tiles="parallel", count_wide_band=wide))):
+        for tag, opt in (("serial", dict(count_long_tiles="serial")), ("parallel", dict(count_long_tiles="parallel", count_wide_band=wide))):
             c, sc, m = count_pass(kw, dict(opt, segment_length=S))
             if tag == "parallel":
                 # (a view without instances launches no work-list workgroup: its meta words are whatever the allocator left there)

@@ -14,7 +14,7 @@ run --n-gaussians 3000000 --mode fwd --steps 100 --no-literal
 run --n-gaussians 3000000 --mode count --steps 100
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1
-run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1 --long-tiles parallel --segment-length 2048
+run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1 --count-long-tiles parallel --segment-length 2048
 run --n-gaussians 3000000 --mode count --steps 100 --scale 0.0045
 run --n-gaussians 3000000 --mode fwdbwd --steps 60 --no-fuse
 run --n-gaussians 3000000 --mode fwdbwd --steps 100 --exact-exp --no-literal
