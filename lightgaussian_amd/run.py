@@ -96,7 +96,7 @@ def _prune_list(gaussians, scene, pipe, background):
     import torch
     from . import prune as lg_prune
     from . import dp
-    dp.assert_same_count(gaussians.get_xyz.shape[0])     # data-parallel run: the collectives below are sized by N
+    dp.assert_same_count(gaussians.get_xyz.shape[0], values=gaussians.get_xyz)     # data-parallel run: the collectives below are sized by N
     with torch.no_grad():       # (the reference's first view is not detached, prune.py:137-141; nothing downstream differentiates it)
         return lg_prune.prune_list_sharded(gaussians, scene, pipe, background)
 
@@ -132,7 +132,7 @@ def _prune_gaussians(self, percent, import_score):
     else:
         lg_prune.prune_points(self, lg_prune.prune_mask(percent, import_score))
     from . import dp
-    dp.assert_same_count(self.get_xyz.shape[0], "Gaussians after prune_gaussians")
+    dp.assert_same_count(self.get_xyz.shape[0], "Gaussians after prune_gaussians", values=self.get_xyz)
 
 
 class _LazyNegDist:
