@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured-copy ceiling is 6290
-PROFILE_ROUND = "r05"  # profiles/<round>_profile_<mode>.json + <round>_<mode>_kernel_stats.csv: the rocprof evidence the roofline quotes
+PROFILE_ROUND = "r06"  # profiles/<round>_profile_<mode>.json + <round>_<mode>_kernel_stats.csv: the rocprof evidence the roofline quotes
 
 
 def parse():
@@ -651,6 +651,7 @@ def main():
     extra["timed_seconds"] = round(elapsed, 4)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * KV * args.steps / elapsed  # whole-job views/s: every rank did `steps` steps of KV views
+    extra["value_contract_region"] = round(value, 3)     # exactly --steps steps between the barriers (the driver's K); `value` is the same loop run for ~1 s when that region is under 0.5 s
     if "steady_state" in extra:
         # r2 verdict: a timed region of a few tens of ms is a burst (clocks have not settled); `value` is the sustained loop of the
         # SAME step, and the contract's K-step region is reported beside it
@@ -817,28 +818,35 @@ def main():
         use_rocprof = bool(ent and ent.get("avg_ns"))
         time_ms = ent["avg_ns"] * 1e-6 if use_rocprof else bracket_ms
         avg_s = time_ms * 1e-3
-        nbytes = ab.get(dom, 0)
+        # The byte model of `achieved` / `frac` is SURVEY.md 8d's (r5 verdict: the contract's figure, not the builder's): per kernel, the terms
+        # of B_fwd / B_bwd that belong to it.  The library's own accounting of what its kernels have to move (the sorted key and the
+        # tile rectangle it also reads, the 48-byte gradient row it writes) stays beside it as bytes_model.library.
+        s8d = {"blend_bwd": ("76R+20P (SURVEY 8d B_bwd: instance re-read 40 + gradient scatter 36 per instance; dL/dcolor 12 + state 8 per pixel)", 76 * R + 20 * P),
+               "blend_fwd": ("40R+20P (SURVEY 8d B_fwd: blend gather 40 per instance; colour 12 + final_T 4 + n_contrib 4 per pixel)", 40 * R + 20 * P),
+               "blend_fwd_count": ("40R+20P+8N (SURVEY 8d B_fwd + count pass: blend gather 40 per instance, 20 per pixel, count + score 8 per Gaussian)", 40 * R + 20 * P + 8 * N),
+               "preprocess": ("16N+(104+12M)V (SURVEY 8d B_fwd: per Gaussian 16; per visible Gaussian 76 + 12 M, + 28 saved for the backward)", 16 * N + (104 + 12 * M) * vis),
+               "preprocess_bwd": ("(108+12M)V+(92+12M)N (SURVEY 8d B_bwd: per-visible re-reads, dense gradient writes + zero-init of the scatter targets)", (108 + 12 * M) * vis + (92 + 12 * M) * N),
+               "sort": ("24R (SURVEY 8d: ideal one-pass sort read + write)", 24 * R), "duplicate": ("12R (SURVEY 8d: key / value write)", 12 * R)}.get(dom)
+        lib_models = {"blend_bwd": "104R+20P (per instance sorted key 8 + tile rect 16 + blend record 36 + gradient row 44; per pixel 20)",
+                      "blend_fwd": "44R+20P (per instance sorted key 8 + blend record 36; per pixel 20)",
+                      "blend_fwd_count": "44R+8N (significance-only pass: sorted key 8 + blend record 36 per instance, count + score 8 per Gaussian, no per-pixel outputs)"}
+        nbytes_lib = ab.get(dom, 0)
+        nbytes = s8d[1] if s8d else nbytes_lib
         achieved = nbytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        # the byte model, spelled out, with SURVEY 8d's own terms for the same kernel beside it
-        models = {"blend_bwd": ("104R+20P (DESIGN 5: per instance sorted key 8 + tile rect 16 + blend record 36 + gradient row 44; per pixel 20)",
-                                "76R+20P (SURVEY 8d: instance re-read 40 + gradient scatter 36; per pixel 20)", 76 * R + 20 * P),
-                  "blend_fwd": ("44R+20P (DESIGN 5: per instance sorted key 8 + blend record 36; per pixel 20)",
-                                "40R+20P (SURVEY 8d: blend gather 40 per instance; per pixel 20)", 40 * R + 20 * P),
-                  "blend_fwd_count": ("44R+8N (DESIGN 5; significance-only pass: sorted key 8 + blend record 36 per instance, count + score 8 per Gaussian, no per-pixel outputs)",
-                                      "40R+20P+8N (SURVEY 8d: count_render that also returns the image)", 40 * R + 20 * P + 8 * N)}.get(dom)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_symbol": sym, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(time_ms, 4),
-                              "time_base": (f"rocprofv3 --kernel-trace --stats AverageNs of {sym} in {stats_file} (build-matched)" if use_rocprof else
-                                            "in-library hipEvent bracket of this run (no build-matched rocprof profile of this workload is committed)"),
+                              "time_base": (f"rocprofv3 --kernel-trace --stats AverageNs of {sym} in {stats_file} (build-matched" +
+                                            (", ONE view in flight: tools/gpu_profile.sh count --count-streams 1" if args.mode == "count" else "") + ")" if use_rocprof else
+                                            "in-library hipEvent bracket of this run, one view in flight (no build-matched rocprof profile of this workload is committed)"),
                               "hipevent_bracket_ms": round(bracket_ms, 4),
                               "frac_by_hipevent_bracket": round(nbytes / (bracket_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bracket_ms > 0 else None,
                               "units": {"N": N, "V_visible": vis, "R_instances": R, "P_pixels": P, "M_sh_coeffs": M},
-                              "recompute": "achieved = algorithmic_bytes_per_launch / avg_launch_ms; frac = achieved / peak",
+                              "recompute": "achieved = algorithmic_bytes_per_launch / avg_launch_ms; frac = achieved / peak; algorithmic_bytes_per_launch = bytes_model.used evaluated at `units`",
                               "profile": pmeta}
-        if models:
-            result["roofline"]["bytes_model"] = {"used": models[0], "survey_8d": models[1], "survey_8d_bytes": models[2],
-                                                 "frac_survey_8d": round(models[2] / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else None}
+        result["roofline"]["bytes_model"] = {"used": s8d[0] if s8d else f"library accounting of {dom} (no SURVEY 8d term names this kernel)",
+                                             "library": lib_models.get(dom), "library_bytes": nbytes_lib,
+                                             "frac_library": round(nbytes_lib / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else None}
         # HBM traffic and VALU instruction counts of the dominant kernel from the committed PMC passes of THIS build
         # (tools/gpu_profile.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs; FETCH_SIZE doubled per the gfx950
         # wide-read correction).  Another build (any kernel source changed since) => traffic null, stale true -- never last round's counters.

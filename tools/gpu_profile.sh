@@ -20,8 +20,8 @@ S=$(find gpurun_out/prof_$MODE -name '*kernel_stats.csv' | head -1)
 C() { find gpurun_out/pmc_${MODE}_$1 -name '*counter_collection.csv' | head -1; }
 python tools/profile_summary.py --mode $MODE --stats $S --fetch $(C 1) --write $(C 2) --sq $(C 3) $(C 4) $(C 5) $(C 6) $(C 7) \
   --command "rocprofv3 [--kernel-trace --stats | --pmc <set>] -- python bench.py --mode $MODE --no-cpu-baseline --no-roofline --no-literal $* (tools/gpu_profile.sh)" \
-  > gpurun_out/${PROFILE_TAG:-r05}_profile_$MODE.json
-cp $S gpurun_out/${PROFILE_TAG:-r05}_${MODE}_kernel_stats.csv
-head -c 1200 gpurun_out/${PROFILE_TAG:-r05}_profile_$MODE.json; echo
+  > gpurun_out/${PROFILE_TAG:-r06}_profile_$MODE.json
+cp $S gpurun_out/${PROFILE_TAG:-r06}_${MODE}_kernel_stats.csv
+head -c 1200 gpurun_out/${PROFILE_TAG:-r06}_profile_$MODE.json; echo
 # the summary and the stats CSV are what travels back (gpurun merges at most 64 MiB); the raw rocprofv3 output stays on the box
 rm -rf gpurun_out/prof_$MODE gpurun_out/pmc_${MODE}_[0-9]*

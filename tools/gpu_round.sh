@@ -52,4 +52,4 @@ timeout -s KILL 300 python examples/finetune_step.py --n-gaussians 3000000 --ite
 timeout -s KILL 300 python examples/finetune_step.py --n-gaussians 3000000 --iters 40 --fused-adam 2>&1 | tail -1 | cut -c1-300
 run --n-gaussians 3000000 --mode fwdbwd --steps 60 --spatial-order --no-literal
 bash tools/gpu_profile.sh fwdbwd 2>&1 | tail -3 | cut -c1-200
-bash tools/gpu_profile.sh count 2>&1 | tail -3 | cut -c1-200
+bash tools/gpu_profile.sh count --count-streams 1 2>&1 | tail -3 | cut -c1-200
