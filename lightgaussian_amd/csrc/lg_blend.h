@@ -992,6 +992,70 @@ __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float*
     __builtin_amdgcn_wave_barrier();                // (the next entry overwrites `red`)
 }
 
+// Round 6 variant (-DLG_K7_PAIR_REDUCE; r5 verdict item 4a, measured A/B: EXPERIMENTS.md): TWO contributing entries per reduction pass.  The
+// 9 x 4 = 36 (row, quarter) sums of one entry leave 28 lanes idle; with two entries, values 0..7 of both make 16 rows -- 64 (row, quarter)
+// pairs, every lane adds usefully -- and the two ninth values (p[8] of A and of B) are folded in registers: one v_permlane32_swap puts A's
+// upper half under its lower half and B's beside it, one add, then five DPP adds inside the 32-lane halves.  An entry's first eight partial
+// sums go to LDS the moment the entry is finished (rows 0..7 for the first of a pair, 8..15 for the second; p[8] of the first waits in one
+// register); the second one's arrival triggers the pass.  13 instead of 17 vector and 11 instead of 14 LDS instructions per entry.
+// Same addends per row, the same association for values 0..7 (quarter sums, then the two quad steps); p[8] is summed in another order:
+// equal up to float rounding, deterministic.
+__device__ __forceinline__ void k7_pair_store(const float (&p)[9], float* red, uint32_t half, uint32_t lane)
+{
+#pragma unroll
+    for (int v = 0; v < 8; v++) red[(half * 8u + (uint32_t)v) * LG_RED_STRIDE + lane] = p[v];
+}
+// lane 31 <- sum over lanes of x, lane 63 <- sum over lanes of y
+__device__ __forceinline__ float k7_fold_two(float x, float y)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);   // r[0] = {x lo, y lo}, r[1] = {x hi, y hi}
+    float z = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    z = dpp_add<0x111, 0xf>(z); // row_shr:1
+    z = dpp_add<0x112, 0xf>(z); // row_shr:2
+    z = dpp_add<0x114, 0xf>(z); // row_shr:4
+    z = dpp_add<0x118, 0xf>(z); // row_shr:8   -> lane 15 of every row holds the row total
+    z = dpp_add<0x142, 0xa>(z); // row_bcast:15 into rows 1, 3 -> lanes 31 and 63 hold the totals of their halves
+    return z;
+}
+// rows 0..7 = entry A (stage column offA), rows 8..15 = entry B (offB), p8a / p8b their ninth values
+__device__ __forceinline__ void k7_pair_reduce(float* red, float* dst, uint32_t offA, uint32_t offB, float p8a, float p8b, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t r = lane >> 2, q = lane & 3u;
+    const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
+    const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+    float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+              (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+    s = dpp_add<0xB1, 0xf>(s);
+    s = dpp_add<0x4E, 0xf>(s);
+    const float z = k7_fold_two(p8a, p8b);
+    if (q == 0u) dst[(r & 7u) * LG_Q + (r < 8u ? offA : offB)] = s;
+    if ((lane & 31u) == 31u) dst[8u * LG_Q + (lane < 32u ? offA : offB)] = z;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // (the next entries overwrite `red`)
+}
+// a pair that never got its second entry (end of a batch): rows 0..7 of LDS + p8a, the single-entry association
+__device__ __forceinline__ void k7_pair_flush(float* red, float* dst, uint32_t offA, float p8a, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t r = (lane >> 2) & 7u, q = lane & 3u;
+    const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
+    const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+    float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+              (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+    s = dpp_add<0xB1, 0xf>(s);
+    s = dpp_add<0x4E, 0xf>(s);
+    const float z = k7_fold_two(p8a, 0.0f);
+    if (q == 0u && lane < 32u) dst[r * LG_Q + offA] = s;
+    if (lane == 31u) dst[8u * LG_Q + offA] = z;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Round 5 variant of the reduction (-DLG_K7_QUAD_REDUCE; measured A/B): K7's LDS pipe is as busy as its vector units --
 // per contributing entry the transposition above costs 9 ds_write_b32 (36 LDS cycles: the store path moves 2 cycles per source dword
 // per wave-instruction whatever the lanes do) + 4 ds_read_b128 (16) + 1 ds_write_b32 (4), on top of the 10 of the record's broadcast
@@ -1149,7 +1213,11 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     // its last read): 256 bytes of LDS less per wave, 6800 in all (round 4: K7 0.692 -> 0.682 ms bracketed.  Six waves per SIMD on top
     // of it -- 80 VGPRs, 24 workgroups per CU now fit -- change nothing further, 0.683: measured again, as in round 3)
     float* const q2 = stage + 8 * LG_Q;
+#ifdef LG_K7_PAIR_REDUCE
+    __shared__ __attribute__((aligned(16))) float red[16 * LG_RED_STRIDE];
+#else
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
+#endif
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
     if (meta[2] != (uint32_t)S) return;           // another segment length than the forward's (see lg_preprocess_bwd)
     const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
@@ -1247,6 +1315,11 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             // (round 4, measured: 3 / 4 / 5 waves per SIMD run this kernel in 0.862 / 0.724 / 0.669 ms -- it is sensitive to latency,
             //  not only to instruction count.  Requesting the NEXT entry's record before the reduction of the current one, so that the
             //  broadcast read is off the chain, changed nothing: 0.662-0.667 vs 0.664-0.670 ms)
+#ifdef LG_K7_PAIR_REDUCE
+            bool have_a = false;                   // scalar: the first entry of a pair is parked (rows 0..7 of `red`, p8a, column ja)
+            float p8a = 0.0f;
+            uint32_t ja = 0;
+#endif
             for (uint64_t any = (M0 | M1) | (M2 | M3); any != 0;) {
                 const int jcur = 63 - __builtin_clzll(any);            // back to front
                 any &= ~(1ull << jcur);
@@ -1284,12 +1357,19 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                 if (cmask != 0) {
 #ifdef LG_K7_QUAD_REDUCE
                     wave_reduce9_quad(p, red, stage, (uint32_t)jcur, lane);
+#elif defined(LG_K7_PAIR_REDUCE)
+                    if (EXACT) wave_reduce9_via_lds(p, red, stage, (uint32_t)jcur, lane);       // (the canonical backward keeps the published association)
+                    else if (!have_a) { k7_pair_store(p, red, 0u, lane); p8a = p[8]; ja = (uint32_t)jcur; have_a = true; }
+                    else { k7_pair_store(p, red, 1u, lane); k7_pair_reduce(red, stage, ja, (uint32_t)jcur, p8a, p[8], lane); have_a = false; }
 #else
                     wave_reduce9_via_lds(p, red, stage, (uint32_t)jcur, lane);
 #endif
                     hitmask |= 1ull << jcur;
                 }
             }
+#ifdef LG_K7_PAIR_REDUCE
+            if (have_a) k7_pair_flush(red, stage, ja, p8a, lane);
+#endif
             __builtin_amdgcn_wave_barrier();
         }
         if (lane < nbt) {
