@@ -100,8 +100,6 @@ def parse():
                     "are cut into independent (tile, segment) work items of the backward")
     ap.add_argument("--long-tiles", choices=["serial", "auto", "parallel"], default="auto", help="rasterizer option long_tiles (walk of outlier tile lists in the forward)")
     ap.add_argument("--count-long-tiles", choices=["serial", "parallel"], default="serial", help="rasterizer option count_long_tiles (the same for the significance-only count pass)")
-    ap.add_argument("--bwd-splat-parallel", action="store_true", help="rasterizer option bwd_splat_parallel: the round-5 PROTOTYPE of the backward blend on the other "
-                    "parallel axis (lg_blend_bwd_splat: lane = list entry, pixel state marching through the wave); measurement only, DESIGN 22.1")
     ap.add_argument("--spatial-order", action="store_true", help="NOT the frozen workload: the same Gaussians permuted into Morton order of their "
                     "centres (lightgaussian_amd.synthetic.morton_permutation) -- what ordering a model spatially is worth; reported as a separate measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -307,7 +305,6 @@ def main():
     rasterizer.set_option("segment_length", args.segment_length)
     rasterizer.set_option("long_tiles", args.long_tiles)
     rasterizer.set_option("count_long_tiles", args.count_long_tiles)
-    rasterizer.set_option("bwd_splat_parallel", bool(args.bwd_splat_parallel))
     if args.sync_free != "default":
         rasterizer.set_option("sync_free", False if args.sync_free == "off" else "validated")
     N, W, H, M = args.n_gaussians, args.width, args.height, (args.sh_degree + 1) ** 2
@@ -799,7 +796,7 @@ def main():
         # committed `rocprofv3 --kernel-trace --stats` summary of the same command, PROVIDED that profile was taken from the very
         # library now loaded (lg_build_id) on this workload; otherwise the live in-library hipEvent bracket (which reads ~14 %
         # above rocprof on the VALU-bound blend kernels).  Both are always printed.
-        sym = {"blend_bwd": "lg_blend_bwd_splat" if (args.bwd_splat_parallel and not args.exact_exp) else "lg_blend_bwd<false>" if not args.exact_exp else "lg_blend_bwd<true>",
+        sym = {"blend_bwd": "lg_blend_bwd<false>" if not args.exact_exp else "lg_blend_bwd<true>",
                "blend_fwd": "lg_blend_fwd<false, 0, false, true>",
                "blend_fwd_count": "lg_blend_fwd<true, %d, true, false>" % {"opacity": 0, "one": 0, "alpha": 2, "alpha_t": 3}[args.weight_policy],
                "preprocess": "lg_preprocess<true, true>", "preprocess_bwd": "lg_preprocess_bwd<true, true>"}.get(dom)

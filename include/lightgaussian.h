@@ -36,7 +36,7 @@ extern "C" {
 
 /* 7 (round 6): lg_view.count_sum (running hit count fused into the score kernel); the ALPHA / ALPHA_T weight policies are exact
  *    64-bit fixed-point sums (Q24.40; out_score bit-reproducible, out_count / out_score written by lg_score_slots) instead of
- *    float atomics; images beyond 2^24 pixels are refused for them.
+ *    float atomics; images beyond 2^24 pixels are refused for them.  LG_FLAG_BWD_SPLAT_PARALLEL (prototype kernel) removed.
  * 6 (round 5): geom buffer layout of round 4 ([N][9] SH direction Jacobian, counters[9]), LG_FLAG_SAVE_SH_JACOBIAN as part of the
  *    forward / backward contract, lg_debug_* moved to lightgaussian_debug.h (all three shipped under 5 -- ADVICE r4), plus this
  *    round's additions: lg_backward's rgb_only mode, lg_sh_grad_from_rgb, LG_FLAG_BWD_SPLAT_PARALLEL.
@@ -89,10 +89,7 @@ enum {
     LG_FLAG_COUNT_WIDE_BAND = 8192, /* tests only: the parallel long-tile walk of the significance-only pass compares regrouped transmittances with
                                        the 1e-4 threshold through an error band; this widens the band 4096 x, sending a fifth of the saturating pixels
                                        through the exact fix-up pass instead of a handful per view.  Counts must not change. */
-    LG_FLAG_BWD_SPLAT_PARALLEL = 4096, /* lg_backward, hardware-exp path: run the round-5 PROTOTYPE of the backward blend on the other
-                                          parallel axis (lg_blend_bwd_splat: lane = list entry, pixel state marching through the wave) instead of
-                                          lg_blend_bwd.  Same gradients up to float rounding.  Measured slower on every scene tried;
-                                          kept as a cross-check of the product kernel, never set by default. */
+    /* (4096 was LG_FLAG_BWD_SPLAT_PARALLEL, the round-5 prototype of the backward blend on the other parallel axis: removed in ABI 7) */
     LG_FLAG_RAW_PARAMS = 8 /* "fused getters" (SURVEY 8f row 1): the inputs are GaussianModel's RAW parameters and the
                               activations of scene/gaussian_model.py:98-118 run inside the kernels: scales = log-scales (exp),
                               rotations = unnormalised quaternions (normalize), opacities = logits (sigmoid), shs = _features_dc

@@ -23,7 +23,6 @@ FLAG_DEBUG, FLAG_FAST_EXP, FLAG_PROFILE, FLAG_RAW_PARAMS, FLAG_SKIP_COLOR, FLAG_
 FLAG_NARROW_KEY, FLAG_SORT_ALL_BITS, FLAG_K1_LDS = 64, 128, 256
 FLAG_LONG_SERIAL, FLAG_LONG_PARALLEL = 512, 1024
 FLAG_SAVE_SH_JACOBIAN = 2048
-FLAG_BWD_SPLAT_PARALLEL = 4096
 FLAG_COUNT_WIDE_BAND = 8192
 ABI_VERSION = 7     # include/lightgaussian.h LG_ABI_VERSION this binding was written against (load() refuses another)
 

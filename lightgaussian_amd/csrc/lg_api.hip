@@ -208,15 +208,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
     if (N > 0) {
         {
             ProfScope ps(prof, "preprocess", stream);
-            // K1 runs FASTER with fewer waves in flight (round 4, measured on one box by padding its LDS: 20 waves per CU -- what its
-            // 92 VGPRs allow -- 0.233 ms, 15: 0.217, 13: 0.201, 12: 0.1995, 11: 0.203, 7: 0.220, 3: 0.34; C2 0.082 -> 0.074, 6 M at 1600x1060 0.444 ->
-            // 0.394, heavy-tailed scene 0.230 -> 0.195): every visible lane reads
-            // its 180-byte SH row as twelve 16-byte pieces, and with all twenty waves' rows in flight the pieces of one cache line
-            // are served by several fetches of that line.  Unused dynamic LDS caps the kernel at 12 waves per CU.
-            // (K9 is the opposite: capped below its 13 waves per CU it slows down at once, 0.262 -> 0.283 ms at 11.)
-            // Only where K1 reads SH rows: the significance-only pass (LG_FLAG_SKIP_COLOR) and precomputed colours have no such reads,
-            // and there the reserved LDS only keeps other views' kernels off the CU (significance pass, A/B on one box: 1605 views/s
-            // with the cap, 1667 without, four views in flight; 1513 / 1590 with one).
+            // K1 runs faster with FEWER waves in flight where it reads SH rows: unused dynamic LDS caps it at 12 waves per CU there (the sweep,
+            // K9's opposite behaviour and the significance pass's A/B: EXPERIMENTS.md, "K1 / K9")
             const size_t k1_dyn = (g->shs && !g->colors_precomp && !(v->flags & LG_FLAG_SKIP_COLOR)) ? LG_K1_PAD_LDS : 0;
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
     lg_preprocess<RAWP, DIR><<<nblk, LG_PP, (DIR) ? k1_dyn : 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
@@ -362,12 +355,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
 #undef LAUNCH_FWD
     }
     KCHECK("lg_blend_fwd");
-    // (round 4, measured and rejected -- two ways of letting these kernels share the device through a second HIP stream.  (1) The
-    //  long-tile chain -- work list, lg_tile_sort_long, the two launches below -- on a stream of its own beside lg_blend_fwd, joined by
-    //  events: uniform scene 650 vs 650 views/s fwd+bwd, heavy-tailed 522 -> 528, fwd-only 1585 -> 1553: what the event round trip costs
-    //  is what the three (mostly empty) launches cost, and on the heavy scene the two grids just share the CUs.  (2) Every view's
-    //  lg_blend_fwd<COUNT> on ONE stream, the memory-bound front of up to six views on others: significance pass 1596 vs 1587 views/s
-    //  at four views in flight.  Kernels that each fill the machine do not overlap into max(a, b) here; they add.)
+    // (a second HIP stream for the long-tile chain / for the memory-bound front of other views: EXPERIMENTS.md, "streams")
     if (par_long && cnt_par) {
         ProfScope ps(prof, "blend_fwd_count_long", stream);
         const uint32_t pgrid = (uint32_t)std::min<int64_t>((int64_t)ntiles + cap / S + 1, LG_PAR_GRID);
@@ -487,10 +475,7 @@ static int backward_impl(const lg_view* v, const lg_gaussians* g, const int32_t*
     // buffer by the forward: one extra workgroup of lg_blend_fwd)
     if (R > 0) {
         ProfScope ps(prof, "blend_bwd", stream);
-        if (fast && (v->flags & LG_FLAG_BWD_SPLAT_PARALLEL))
-            lg_blend_bwd_splat<<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
-                                                            img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
-        else if (fast)
+        if (fast)
             lg_blend_bwd<false><<<max_items, 64, 0, stream>>>(W, H, gx, S, bin.work, bin.meta, bin.ranges, bin.entries, gid_mask, geo.tinfo, geo.rec, v->bg,
                                                               img.final_T, img.n_contrib, dL_dcolor, bin.ckpt, rows);
         else

@@ -10,11 +10,8 @@
 
 // ------------------------------------------------------------------------------------------------
 // tile <-> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only).
-// Neighbouring tiles share Gaussians, so each XCD (own 4 MB L2) is given runs of 4 consecutive tiles -- but runs from
-// all over the image, interleaved with the other XCDs.  (Giving each XCD one contiguous eighth of the image, the first
-// design, was measured 15 % SLOWER on both blend kernels than no remapping at all: work per image band is uneven, and
-// a static band per XCD turns that into idle XCDs.  Interleaved runs of 1, 2, 4, 8 or 32 tiles all measure the same
-// within noise -- these kernels are VALU-bound, the L2 affinity buys nothing measurable; runs of 4 are kept.)
+// Neighbouring tiles share Gaussians, so each XCD (own 4 MB L2) is given runs of 4 consecutive tiles, interleaved with the other XCDs' runs
+// over the whole image (a contiguous band per XCD and other run lengths: EXPERIMENTS.md, "tile -> XCD map").
 // The map is a bijection on [0, ntiles_pad) for ntiles_pad a multiple of 32; callers guard tile < ntiles.
 #ifndef LG_XCD_RUN_LOG2
 #define LG_XCD_RUN_LOG2 2 // runs of 4 consecutive tiles per XCD
@@ -43,9 +40,7 @@ __device__ __forceinline__ float guard_alpha(float alpha, float opacity, float p
     }
     return alpha;
 }
-// (round 4, measured and rejected: the guard folded into the threshold test -- two compares against the ends of the doubtful band
-//  instead of subtract + |.| compare + threshold compare.  One VALU instruction less per pair (K7 417 -> 403 M, K6 209 -> 203 M per
-//  launch) but one scalar mask operation more, and the scalar unit is the busier one: K6 0.308 -> 0.313 ms, K7 unchanged.)
+// (the guard folded into the threshold test: EXPERIMENTS.md, "K6 / K7 pair step")
 
 // Does the 8 x 8 pixel block [x0, x0 + 7] x [y0, y0 + 7] hold a pixel the splat can reach (alpha >= 1/255)?
 // First the axis-aligned box of the alpha >= 1/255 ellipse (hx, hy from lg_project; inf = culling off), then the ellipse
@@ -82,47 +77,11 @@ __device__ __forceinline__ bool lg_block_hit(const float4& r0, const float4& r1,
     return box && (reach || !e.cull);
 }
 
-// Select-based (no divergent control flow) front-to-back step.  Same canonical operations as lg_blend_pair on
-// every lane that contributes, so results are bit-identical; rejected lanes compute and discard.
-template <bool EXACT, bool COLOR = true>
-__device__ __forceinline__ bool fwd_pair(const float4& a, const float4& b, const float4& c, bool live, float pxf, float pyf, float& T,
-                                         float& C0, float& C1, float& C2, bool& done, uint32_t& last, uint32_t rel, float& alpha_out,
-                                         float& w_out)
-{
-    const float dx = a.x - pxf, dy = a.y - pyf;
-    const float power = fmaf(fmaf(a.z, dx, a.w * dy), dx, (b.x * dy) * dy);
-    // hardware-exp variant: no clamp of the exponent -- lanes with power > 0 are rejected by `ok` below whatever exp returned
-    // (inf -> alpha 0.99, NaN compares false), and the guard's rare branch clamps for itself
-    const float ex = EXACT ? lg_exp(fminf(power, 0.0f)) : __expf(power);
-    float alpha = fminf(LG_ALPHA_MAX, b.y * ex);
-    if (!EXACT) alpha = guard_alpha(alpha, b.y, power);
-    const bool ok = live && (power <= 0.0f) && (alpha >= LG_ALPHA_MIN);
-    const float test_T = T * (1.0f - alpha);
-    const bool sat = ok && (test_T < LG_T_MIN);
-    // (ok && !sat) written as an exclusive-or of the two lane masks: hipcc evaluated `!sat` with a second v_cmp (ngt) next to the
-    // one for `sat` -- compares cost 1.7x an fma on gfx950 -- where one s_xor of the masks does
-    const bool contrib = ok != sat;
-    // one select on the weight instead of three on the colours: fmaf(rgb, 0, C) == C bit for bit (finite rgb)
-    if (COLOR) {   // significance-only passes (LG_FLAG_SKIP_COLOR) carry no colour at all
-        const float w = contrib ? alpha * T : 0.0f;
-        C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(c.x, w, C2);
-        w_out = w;
-    }
-    T = contrib ? test_T : T;
-    last = contrib ? rel : last;
-    done = done || sat;
-    alpha_out = alpha;
-    return contrib;
-}
-
-// The same step with the lanes' `done` state as ONE scalar lane mask (round 5).  fwd_pair carries `done` as a per-lane bool through the
-// pair loop; hipcc lowers a loop-carried i1 by re-merging it with exec on every iteration (s_andn2 + s_and + s_or) on top of the xor for
-// `!done`: 13 scalar instructions per pair step, and the scalar unit -- one per CU, shared by all its waves -- is as busy as the vector
-// units in this kernel (0.53 scalar instructions per CU-cycle; six dummy s_add per step cost 8.3 %).  Here every compare is
-// balloted, the masks are combined as plain 64-bit scalars (s_andn2, s_and, s_xor, s_or: four operations) and the contributing set goes
-// back to a lane predicate through llvm.amdgcn.inverse.ballot, which costs no instruction.  9 scalar instructions per pair step, the
-// vector stream unchanged; every compare is the same compare, so counts, scores and images are bit-identical to fwd_pair (kept above as
-// the cross-check: -DLG_K6_BOOL_DONE builds the old form).  Returns the mask of the lanes the entry contributed to.
+// Select-based (no divergent control flow) front-to-back step of one list entry for the 64 pixels of a wave.  The lanes' `done` state
+// (saturated or outside the image) is ONE scalar lane mask: every compare is balloted, the masks are combined as 64-bit scalars and the
+// contributing set goes back to a lane predicate through llvm.amdgcn.inverse.ballot (no instruction) -- 9 scalar instructions per pair step
+// where a loop-carried per-lane bool cost 13 (EXPERIMENTS.md, "K6 / K7 pair step").  Rejected lanes compute and discard; contributing lanes
+// run the canonical operations of the oracle, so results are bit-identical.  Returns the mask of the lanes the entry contributed to.
 template <bool EXACT, bool COLOR = true>
 __device__ __forceinline__ uint64_t fwd_pair_m(const float4& a, const float4& b, const float4& c, uint64_t& donem, float pxf, float pyf, float& T,
                                                float& C0, float& C1, float& C2, uint32_t& last, uint32_t rel, float& alpha_out, float& w_out)
@@ -220,13 +179,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         lg_work_order_body(ntiles, S, ranges, work, meta, scratch, scratch + 256, threadIdx.x, 256, par_work, par_min, par_arrived);
         return;
     }
-    // (round 4, measured and rejected -- commit 'prototype: quarter-wave K6', profiles/r04_proto_k6_quarter_wave_profile_fwdbwd.json: every
-    //  16-lane row walking the entries of its own 4 x 4 block, four (entry, block) pairs per pass.  A splat of this scene covers 52
-    //  pixels in 3.3 blocks of 8 x 8 or 6.7 blocks of 4 x 4, so the pair passes halve; but every tile-entry is then tested against 16
-    //  blocks instead of 4, the per-row queues have to be built, and the entry index is one more dependent LDS read: 209 -> 197 M VALU
-    //  instructions only, 12 -> 13.7 KB of LDS per workgroup, 0.264 -> 0.283 ms.  Counts, scores and images stayed bit-identical.)
-    // (longest-list-first dispatch like the backward's was measured here: 0.292 vs 0.298 ms, noise -- 4 waves per tile
-    // already give 4 rounds of wave slots; the XCD-interleaved static map stays)
+    // (quarter-wave walk, longest-list-first dispatch: EXPERIMENTS.md, "K6 structure")
     const int tile = xcd_tile(blockIdx.x, ntiles_pad);
     if (tile >= ntiles) return;
     const int wave = threadIdx.x >> 6;
@@ -242,11 +195,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
-#ifdef LG_K6_BOOL_DONE
-    bool done = !inside;
-#else
     uint64_t donem = ~__builtin_amdgcn_ballot_w64(inside);    // saturated or outside the image: one scalar mask per wave (fwd_pair_m)
-#endif
     // Long list (more than one segment of S entries): leave a checkpoint record per pixel at the end of every segment --
     // {T there, colour accumulated INSIDE the segment (absolute weights alpha T: a sum of non-negative terms, no
     // cancellation)} -- from which the backward starts each segment independently (lg_blend_bwd).  Record j of this tile is
@@ -263,19 +212,13 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
         uint32_t seg = 0;
         float4* ck = nullptr;
         if (LONG) ck = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256 + pix_in_tile;
-        // (a software pipeline over the batches -- records of batch k + 1 and list entries of batch k + 2 requested before batch
-        // k is blended -- was measured: 0.311 -> 0.320 ms on the uniform scene, 1.356 -> 1.329 ms on the heavy one.  The walk of a
-        // long tile is an arithmetic chain, not a latency chain: ~64 pair evaluations per batch on a lone wave.)
+        // (software pipeline over the batches: EXPERIMENTS.md, "K6 structure")
         for (uint32_t base = range.x; base < range.y; base += LG_Q) {
             if (LONG && base != range.x && (base - range.x) % (uint32_t)S == 0u) {
                 ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
                 seg++; Cs0 = Cs1 = Cs2 = 0.0f;
             }
-#ifdef LG_K6_BOOL_DONE
-            if (__ballot(!done) == 0) break; // every pixel of this wave is saturated or outside
-#else
             if (~donem == 0ull) break;       // every pixel of this wave is saturated or outside
-#endif
             const uint32_t idx = base + lane;
             bool hit = false;
             float4 r0, r1, r2;
@@ -306,22 +249,15 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             auto pair = [&](uint32_t j, float* wrow) {
                 const float4 a = q0[wave][j], b = q1[wave][j], c = q2[wave][j];
                 float alpha = 0.0f, Tprev = T, w = 0.0f;
-#ifdef LG_K6_BOOL_DONE
-                const bool res = fwd_pair<EXACT, COLOR>(a, b, c, !done, pxf, pyf, T, C0, C1, C2, done, last, __float_as_uint(c.y), alpha, w);
-                const uint64_t cm = COUNT ? __ballot(res) : 0ull;
-#else
                 const uint64_t cm = fwd_pair_m<EXACT, COLOR>(a, b, c, donem, pxf, pyf, T, C0, C1, C2, last, __float_as_uint(c.y), alpha, w);
                 const bool res = __builtin_amdgcn_inverse_ballot_w64(cm);
-#endif
                 if (LONG) { Cs0 = fmaf(b.z, w, Cs0); Cs1 = fmaf(b.w, w, Cs1); Cs2 = fmaf(c.x, w, Cs2); }
                 if (COUNT) {
                     if (owned == j) mycnt = (int)__popcll(cm);
                     if (FSCORE) *wrow = res ? (FSCORE == LG_W_ALPHA ? alpha : alpha * Tprev) : 0.0f;
                 }
             };
-            // (round 5, measured and rejected: two pair steps per trip of this loop -- written out by hand, hipcc refuses `#pragma unroll` over the
-            //  convergent ballots behind the guard's branch -- to halve the loop control, three of the nine scalar instructions of a pair step:
-            //  K6 0.2661 / 0.2651 -> 0.2638 / 0.2602 ms bracketed, the count variant 0.365 / 0.3595 -> 0.3616 / 0.3636: noise level, 62 VGPRs instead of 56.)
+            // (two pair steps per loop trip: EXPERIMENTS.md, "K6 / K7 pair step")
             if (FSCORE) {
                 // chunks of LG_WQ_ROWS pair steps, each leaving one row of quantised weights; then the rows are summed (lg_wq_rowsum).  (Rows past
                 // the end of a last, partial chunk hold older weights: their totals go to lanes whose entry is >= nhit, which issue nothing.)
@@ -336,8 +272,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 for (uint32_t j = 0; j < nhit; j++) pair(j, nullptr);
             }
             if (COUNT) {
-                // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide
-                // (round 5 ablation, profiles/r05_call_count_band.log: without these atomics the kernel takes 287 us instead of 328)
+                // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide (their cost: EXPERIMENTS.md, "significance pass")
                 if (!FSCORE) {
                     if (lane < nhit && mycnt > 0) {
                         const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
@@ -899,19 +834,10 @@ lg_count_fixup(int W, int H, int gx, int S, const uint2* __restrict__ par_work, 
     }
 }
 
-// (Round 5, measured and rejected -- profiles/r05_call_count_band.log: the serial walk of the significance-only pass with the HARDWARE exp, the
-//  stop decided through the same kind of error band as above (a factor 1 - alpha differs from its canonical twin by at most 7.6e-7 alpha /
-//  (1 - alpha): v_exp_f32 1 ulp, its argument rounded at |x log2 e| <= 8, lg_exp within 7.8e-8 of exp) and the undecided pixels resolved by
-//  lg_count_exact_pixel from a per-pixel flag plane.  Counts bit-identical to the canonical walk and the oracle on 12 scene families + 40
-//  random scenes, 32 vector instructions per pair step instead of ~45 -- and no faster: lg_blend_count_band 342 us against 333 us for
-//  lg_blend_fwd<COUNT, EXACT> on the uniform scene (the count kernel is not bound by the exp polynomial: without its atomics it takes 287 us,
-//  the colour forward with v_exp 260), 941 + 858 us against 846 on the heavy-tailed scene, where 451 pixels per view had to be resolved one
-//  after the other by the waves that own them.  Removed.)
+// (hardware-exp count walk with an error band: EXPERIMENTS.md, "significance pass")
 // per-view score from the exact integer count (ONE / OPACITY weights): score = lg_seqsum32(weight, count), the float that `count`
 // sequential additions of the weight leave (lg_math.h).
-// (Round 6, measured and rejected -- EXPERIMENTS.md: each workgroup compacting its 256 Gaussians to the hit ones, large counts first, so
-//  that full waves of similar walk length run: 0.040 -> 0.039 ms; the same with 2048 persistent workgroups striding over the chunks: 0.045.
-//  The pass rate did not move with either (1715 .. 1731 views/s, box noise).)
+// (workgroup compaction by count magnitude, persistent workgroups: EXPERIMENTS.md, "significance pass")
 __global__ void __launch_bounds__(256)
 lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restrict__ weight, float* __restrict__ score, int32_t* __restrict__ count_sum)
 {
@@ -992,107 +918,7 @@ __device__ __forceinline__ void wave_reduce9_via_lds(const float (&p)[9], float*
     __builtin_amdgcn_wave_barrier();                // (the next entry overwrites `red`)
 }
 
-// Round 6 variant (-DLG_K7_PAIR_REDUCE; r5 verdict item 4a, measured A/B: EXPERIMENTS.md): TWO contributing entries per reduction pass.  The
-// 9 x 4 = 36 (row, quarter) sums of one entry leave 28 lanes idle; with two entries, values 0..7 of both make 16 rows -- 64 (row, quarter)
-// pairs, every lane adds usefully -- and the two ninth values (p[8] of A and of B) are folded in registers: one v_permlane32_swap puts A's
-// upper half under its lower half and B's beside it, one add, then five DPP adds inside the 32-lane halves.  An entry's first eight partial
-// sums go to LDS the moment the entry is finished (rows 0..7 for the first of a pair, 8..15 for the second; p[8] of the first waits in one
-// register); the second one's arrival triggers the pass.  13 instead of 17 vector and 11 instead of 14 LDS instructions per entry.
-// Same addends per row, the same association for values 0..7 (quarter sums, then the two quad steps); p[8] is summed in another order:
-// equal up to float rounding, deterministic.
-__device__ __forceinline__ void k7_pair_store(const float (&p)[9], float* red, uint32_t half, uint32_t lane)
-{
-#pragma unroll
-    for (int v = 0; v < 8; v++) red[(half * 8u + (uint32_t)v) * LG_RED_STRIDE + lane] = p[v];
-}
-// lane 31 <- sum over lanes of x, lane 63 <- sum over lanes of y
-__device__ __forceinline__ float k7_fold_two(float x, float y)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);   // r[0] = {x lo, y lo}, r[1] = {x hi, y hi}
-    float z = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    z = dpp_add<0x111, 0xf>(z); // row_shr:1
-    z = dpp_add<0x112, 0xf>(z); // row_shr:2
-    z = dpp_add<0x114, 0xf>(z); // row_shr:4
-    z = dpp_add<0x118, 0xf>(z); // row_shr:8   -> lane 15 of every row holds the row total
-    z = dpp_add<0x142, 0xa>(z); // row_bcast:15 into rows 1, 3 -> lanes 31 and 63 hold the totals of their halves
-    return z;
-}
-// rows 0..7 = entry A (stage column offA), rows 8..15 = entry B (offB), p8a / p8b their ninth values
-__device__ __forceinline__ void k7_pair_reduce(float* red, float* dst, uint32_t offA, uint32_t offB, float p8a, float p8b, uint32_t lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t r = lane >> 2, q = lane & 3u;
-    const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
-    const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-    float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
-              (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
-    s = dpp_add<0xB1, 0xf>(s);
-    s = dpp_add<0x4E, 0xf>(s);
-    const float z = k7_fold_two(p8a, p8b);
-    if (q == 0u) dst[(r & 7u) * LG_Q + (r < 8u ? offA : offB)] = s;
-    if ((lane & 31u) == 31u) dst[8u * LG_Q + (lane < 32u ? offA : offB)] = z;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                // (the next entries overwrite `red`)
-}
-// a pair that never got its second entry (end of a batch): rows 0..7 of LDS + p8a, the single-entry association
-__device__ __forceinline__ void k7_pair_flush(float* red, float* dst, uint32_t offA, float p8a, uint32_t lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t r = (lane >> 2) & 7u, q = lane & 3u;
-    const float4* src = reinterpret_cast<const float4*>(red + r * LG_RED_STRIDE + q * 16u);
-    const float4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-    float s = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
-              (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
-    s = dpp_add<0xB1, 0xf>(s);
-    s = dpp_add<0x4E, 0xf>(s);
-    const float z = k7_fold_two(p8a, 0.0f);
-    if (q == 0u && lane < 32u) dst[r * LG_Q + offA] = s;
-    if (lane == 31u) dst[8u * LG_Q + offA] = z;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Round 5 variant of the reduction (-DLG_K7_QUAD_REDUCE; measured A/B): K7's LDS pipe is as busy as its vector units --
-// per contributing entry the transposition above costs 9 ds_write_b32 (36 LDS cycles: the store path moves 2 cycles per source dword
-// per wave-instruction whatever the lanes do) + 4 ds_read_b128 (16) + 1 ds_write_b32 (4), on top of the 10 of the record's broadcast
-// reads.  Here the first two levels stay in registers: two quad_perm v_add_f32_dpp per value leave every quad's sum in all four of its
-// lanes (18 VALU), lane q of a quad picks values q, 4 + q and 8 (6 v_cndmask on constant lane masks) and stores THREE words -- the
-// matrix in LDS is 9 x 16 instead of 9 x 64 -- and lane 4 r + qq finishes row r with ONE ds_read_b128 + 3 adds + 2 quad adds.
-// 29 VALU + 20 LDS cycles per entry instead of 17 + 56.  Same addends, another association: equal up to float rounding, deterministic.
-#define LG_REDQ_STRIDE 20
-#define LG_REDQ_FLOATS (9 * LG_REDQ_STRIDE)
-__device__ __forceinline__ void wave_reduce9_quad(const float (&p)[9], float* red, float* dst, uint32_t dst_off, uint32_t lane)
-{
-    float q[9];
-#pragma unroll
-    for (int v = 0; v < 9; v++) {
-        float x = dpp_add<0xB1, 0xf>(p[v]);          // quad_perm [1,0,3,2]
-        q[v] = dpp_add<0x4E, 0xf>(x);                // quad_perm [2,3,0,1]: every lane of the quad holds the quad's sum
-    }
-    const uint64_t m1 = 0x2222222222222222ull, m2 = 0x4444444444444444ull, m3 = 0x8888888888888888ull;
-    const bool l1 = __builtin_amdgcn_inverse_ballot_w64(m1), l2 = __builtin_amdgcn_inverse_ballot_w64(m2), l3 = __builtin_amdgcn_inverse_ballot_w64(m3);
-    float x0 = l1 ? q[1] : q[0]; x0 = l2 ? q[2] : x0; x0 = l3 ? q[3] : x0;
-    float x1 = l1 ? q[5] : q[4]; x1 = l2 ? q[6] : x1; x1 = l3 ? q[7] : x1;
-    const uint32_t qi = lane & 3u, quad = lane >> 2;
-    red[qi * LG_REDQ_STRIDE + quad] = x0;
-    red[(4u + qi) * LG_REDQ_STRIDE + quad] = x1;
-    red[8u * LG_REDQ_STRIDE + quad] = q[8];          // (the four lanes of a quad store the same word)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t r = min(lane >> 2, 8u);
-    const float4 x = *reinterpret_cast<const float4*>(red + r * LG_REDQ_STRIDE + qi * 4u);
-    float s = (x.x + x.y) + (x.z + x.w);
-    s = dpp_add<0xB1, 0xf>(s);
-    s = dpp_add<0x4E, 0xf>(s);
-    if (qi == 0u && lane < 36u) dst[(lane >> 2) * LG_Q + dst_off] = s;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                // (the next entry overwrites `red`)
-}
+// (two entries per reduction pass, quads summed in registers first, packed adds: EXPERIMENTS.md, "K7 reduction")
 
 // Gradient rows hold MOMENTS, not finished gradients.  With t = G * dL/dalpha per (pixel, Gaussian) pair, dx = x_g - px:
 //   p[0] = sum t dx   p[1] = sum t dy   p[2] = sum t dx^2   p[3] = sum t dx dy   p[4] = sum t dy^2   p[5] = sum t
@@ -1181,10 +1007,7 @@ __device__ __forceinline__ uint64_t bwd_pair_fast(const float4& a, const float4&
     S = am * d + S;
     const float dch = am * Tn;
     const float tdx = t * dx, tdy = t * dy;
-    // (round 5, measured and rejected: a wave-uniform `fresh` flag -- this is the entry's first evaluated sub-block -- under which this tail
-    //  ASSIGNS the nine sums, so that the caller need not zero them (nine v_mov per entry whenever sub-block 0 is not hit, 63 % of the
-    //  entries); only the tail existed twice, not the pair step as in round 3's attempt.  89 VGPRs instead of 83, 49 more vector
-    //  instructions of code: K7 0.5988 / 0.5967 / 0.5908 -> 0.5955 / 0.6095 / 0.6042 ms bracketed, three A/B pairs on one box.  Nothing.)
+    // (a `fresh` flag under which the first sub-block assigns the nine sums: EXPERIMENTS.md, "K7 structure")
     p[0] += tdx;
     p[1] += tdy;
     p[2] += tdx * dx;
@@ -1213,11 +1036,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     // its last read): 256 bytes of LDS less per wave, 6800 in all (round 4: K7 0.692 -> 0.682 ms bracketed.  Six waves per SIMD on top
     // of it -- 80 VGPRs, 24 workgroups per CU now fit -- change nothing further, 0.683: measured again, as in round 3)
     float* const q2 = stage + 8 * LG_Q;
-#ifdef LG_K7_PAIR_REDUCE
-    __shared__ __attribute__((aligned(16))) float red[16 * LG_RED_STRIDE];
-#else
     __shared__ __attribute__((aligned(16))) float red[LG_RED_FLOATS];
-#endif
     if (blockIdx.x >= meta[0]) return;            // the grid is sized for the worst case: tiles + R / S work items
     if (meta[2] != (uint32_t)S) return;           // another segment length than the forward's (see lg_preprocess_bwd)
     const uint2 item = work[blockIdx.x];          // {tile, segment}, longest first (lg_work_order)
@@ -1312,14 +1131,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
             }
             const uint64_t M0 = __ballot(hit[0]), M1 = __ballot(hit[1]), M2 = __ballot(hit[2]), M3 = __ballot(hit[3]);
             __builtin_amdgcn_wave_barrier();
-            // (round 4, measured: 3 / 4 / 5 waves per SIMD run this kernel in 0.862 / 0.724 / 0.669 ms -- it is sensitive to latency,
-            //  not only to instruction count.  Requesting the NEXT entry's record before the reduction of the current one, so that the
-            //  broadcast read is off the chain, changed nothing: 0.662-0.667 vs 0.664-0.670 ms)
-#ifdef LG_K7_PAIR_REDUCE
-            bool have_a = false;                   // scalar: the first entry of a pair is parked (rows 0..7 of `red`, p8a, column ja)
-            float p8a = 0.0f;
-            uint32_t ja = 0;
-#endif
+            // (occupancy sweep, early request of the next record: EXPERIMENTS.md, "K7 structure")
             for (uint64_t any = (M0 | M1) | (M2 | M3); any != 0;) {
                 const int jcur = 63 - __builtin_clzll(any);            // back to front
                 any &= ~(1ull << jcur);
@@ -1344,9 +1156,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                         }
                     }
                 } else {
-                    // (round 3, measured and rejected: dispatching on the lowest hit sub-block so that it ASSIGNS the nine partial
-                    //  sums -- no zeroing: 9 v_mov per entry whenever sub-block 0 is not hit -- made the kernel 7 % SLOWER,
-                    //  0.695 -> 0.745 ms: ten copies of the pair step instead of four, 92 VGPRs)
+                    // (dispatch on the lowest hit sub-block instead of zeroing the sums: EXPERIMENTS.md, "K7 structure")
 #pragma unroll
                     for (int v = 0; v < 9; v++) p[v] = 0.0f;
 #pragma unroll
@@ -1355,21 +1165,10 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
                             cmask |= bwd_pair_fast(a, b, c, rel <= last[s], pxf[s], pyf[s], T[s], Tfb[s], g0[s], g1[s], g2[s], Sd[s], p);
                 }
                 if (cmask != 0) {
-#ifdef LG_K7_QUAD_REDUCE
-                    wave_reduce9_quad(p, red, stage, (uint32_t)jcur, lane);
-#elif defined(LG_K7_PAIR_REDUCE)
-                    if (EXACT) wave_reduce9_via_lds(p, red, stage, (uint32_t)jcur, lane);       // (the canonical backward keeps the published association)
-                    else if (!have_a) { k7_pair_store(p, red, 0u, lane); p8a = p[8]; ja = (uint32_t)jcur; have_a = true; }
-                    else { k7_pair_store(p, red, 1u, lane); k7_pair_reduce(red, stage, ja, (uint32_t)jcur, p8a, p[8], lane); have_a = false; }
-#else
                     wave_reduce9_via_lds(p, red, stage, (uint32_t)jcur, lane);
-#endif
                     hitmask |= 1ull << jcur;
                 }
             }
-#ifdef LG_K7_PAIR_REDUCE
-            if (have_a) k7_pair_flush(red, stage, ja, p8a, lane);
-#endif
             __builtin_amdgcn_wave_barrier();
         }
         if (lane < nbt) {
@@ -1389,174 +1188,7 @@ lg_blend_bwd(int W, int H, int gx, int S, const uint2* __restrict__ work, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K7 on the OTHER parallel axis (round 5 prototype, r4 verdict item 2; LG_FLAG_BWD_SPLAT_PARALLEL, hardware-exp path only):
-// lane = list entry, the pixels' state marches through the wave.  One wave per (tile, segment) work item, as lg_blend_bwd.
-// The item's entries are taken back to front in buckets of 64; lane l of a bucket holds entry 64 k + 63 - l in REGISTERS
-// (position, conic, opacity, colour, its 1-based list position and its pre-sort slot) together with its own nine moment sums.
-// The 256 pixels of the tile stream through the lanes: at step t lane l works on pixel (t - l) mod 256 of bucket (t - l) / 256,
-// whose state {T, S = (colour behind) . dL/dC, dL/dC, T_final (bg . dL/dC), last contributor, pixel centre} arrived from lane
-// l - 1 by ONE DPP wave_shr:1 per value; lane 0 is fed from the wave's pixel table in LDS, lane 63 writes {T, S} back for the
-// next bucket -- a rolling pipeline: 256 steps per bucket + 63 to drain the item, no refill between buckets.  A lane that has
-// seen its 256th pixel writes its 48-byte row once (no wave_reduce9_via_lds, no `stage` / `red` LDS, no hit masks, no zeroing of
-// nine partials per entry) and takes the next bucket's entry from a staging row that was loaded ~190 steps earlier.
-// Same per-pair arithmetic as lg_blend_bwd<false> (bwd_pair_fast, the same include / exclude decisions), moments summed over the
-// pixels in stream order instead of sub-block partials + tree: equal up to float rounding, deterministic run to run.
-// COST MODEL, stated before the first measurement: 9 DPP moves + ~42 pair instructions per step, 256 steps per 64
-// entries = ~204 wave-instructions per (tile, splat) instance against lg_blend_bwd's measured 99 (409.8 M / 4.14 M at C3) -- every
-// splat pays for all 256 pixels of the tile, where the sub-block walk evaluates 1.47 blocks of 64.  Kill criterion: slower than
-// 0.52 ms at C3 with parity green.
-#define LG_DPP_WAVE_SHR1 0x138
-__device__ __forceinline__ float lg_march(float feed, float v)
-{
-    // lane l <- lane l - 1; lane 0 (no source lane, bound_ctrl off) keeps `feed`
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(feed), __float_as_int(v), LG_DPP_WAVE_SHR1, 0xf, 0xf, false));
-}
-
-__global__ void __launch_bounds__(64)
-lg_blend_bwd_splat(int W, int H, int gx, int S, const uint2* __restrict__ work, const uint32_t* __restrict__ meta, const uint2* __restrict__ ranges,
-                   const uint64_t* __restrict__ entries, uint32_t gid_mask, const uint4* __restrict__ tinfo, const float4* __restrict__ rec,
-                   const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                   const float* __restrict__ dL_dpix, const float4* __restrict__ ckpt, float* __restrict__ part)
-{
-    __shared__ float4 pixA[256];                 // {dL/dC r, g, b, T_final (bg . dL/dC)} per pixel of the tile
-    __shared__ float4 pixB[256];                 // {T, S, last contributor (bits), -}: T and S are rewritten by lane 63 bucket after bucket
-    __shared__ float2 pixC[256];                 // pixel centre
-    __shared__ float4 stg[3][LG_Q];              // the NEXT bucket's entries, one staging row per lane
-    if (blockIdx.x >= meta[0]) return;
-    if (meta[2] != (uint32_t)S) return;
-    const uint2 item = work[blockIdx.x];
-    const int tile = (int)item.x;
-    const uint32_t lane = threadIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
-    const uint2 range = ranges[tile];
-    const size_t HW = (size_t)H * W;
-    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
-    const uint32_t n_list = range.y - range.x;
-    if (n_list == 0) return;
-    const uint32_t nseg = (n_list + (uint32_t)S - 1u) / (uint32_t)S;
-    const uint32_t seg_lo = item.y * (uint32_t)S, seg_hi = min(n_list, seg_lo + (uint32_t)S);
-    uint32_t wmax = 0;
-    // ---- pixel table: the start state of lg_blend_bwd (end of the list, or the forward's checkpoints of this segment) ----
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int pxi = tx * LG_TILE + (s & 1) * 8 + (int)(lane & 7), pyi = ty * LG_TILE + (s >> 1) * 8 + (int)(lane >> 3);
-        const bool inside = pxi < W && pyi < H;
-        const size_t pid = (size_t)pyi * W + pxi;
-        const uint32_t pix = ((uint32_t)(s >> 1) * 8u + (lane >> 3)) * 16u + (uint32_t)(s & 1) * 8u + (lane & 7u);
-        float T = inside ? final_T[pid] : 0.0f;
-        const uint32_t last = inside ? n_contrib[pid] : 0u;
-        const float g0 = inside ? dL_dpix[pid] : 0.0f, g1 = inside ? dL_dpix[HW + pid] : 0.0f, g2 = inside ? dL_dpix[2 * HW + pid] : 0.0f;
-        const float Tfb = T * (bgr * g0 + bgg * g1 + bgb * g2);
-        float Sd = 0.0f;
-        if (item.y + 1u < nseg && inside) {
-            const float4* cr = ckpt + (size_t)2 * (range.x / (uint32_t)S) * 256;
-            const float4 here = cr[(size_t)item.y * 256 + pix];
-            float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-            for (uint32_t j = nseg - 1u; j > item.y; j--) {
-                const float4 r = cr[(size_t)j * 256 + pix];
-                b0 += r.y; b1 += r.z; b2 += r.w;
-            }
-            const float inv = 1.0f / here.x;
-            T = here.x;
-            Sd = (b0 * g0 + b1 * g1 + b2 * g2) * inv;
-        }
-        pixA[pix] = make_float4(g0, g1, g2, Tfb);
-        pixB[pix] = make_float4(T, Sd, __uint_as_float(last), 0.0f);
-        pixC[pix] = make_float2((float)pxi, (float)pyi);
-        wmax = max(wmax, last);
-    }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
-    wmax = __builtin_amdgcn_readfirstlane(wmax);
-    if (wmax > seg_hi) wmax = seg_hi;
-    float4* rows = reinterpret_cast<float4*>(part);
-    const int kb_lo = (int)(seg_lo / LG_Q), kb_top = (int)((seg_hi - 1u) / LG_Q);
-    const int kb_hi = wmax > seg_lo ? (int)((wmax - 1u) / LG_Q) : kb_lo - 1;       // last bucket any pixel reached
-    // buckets nobody reached: zero rows (every list entry owns exactly one row)
-    for (int k = kb_top; k > kb_hi; k--) {
-        const uint32_t e = (uint32_t)k * LG_Q + lane;
-        if (e < seg_hi) {
-            const uint32_t id = (uint32_t)entries[range.x + e] & gid_mask;
-            float4* dst = rows + 3 * (size_t)lg_slot_of(tinfo[id], tx, ty);
-            dst[0] = dst[1] = dst[2] = make_float4(0, 0, 0, 0);
-        }
-    }
-    const int nbk = kb_hi - kb_lo + 1;
-    if (nbk <= 0) return;
-    // entry of this lane in bucket-phase b: list position 64 (kb_hi - b) + 63 - lane (the last entry of the bucket sits in lane 0)
-    auto fetch = [&](int b, float4& r0, float4& r1, float4& r2) {
-        const uint32_t e = (uint32_t)(kb_hi - b) * LG_Q + (63u - lane);
-        r0 = r1 = make_float4(0, 0, 0, 0);
-        r2 = make_float4(0, 0, __uint_as_float(0xFFFFFFFFu), 0);
-        if (e < seg_hi) {
-            const uint32_t id = (uint32_t)entries[range.x + e] & gid_mask;
-            const float4 q0 = rec[LG_REC_F4 * (size_t)id], q1 = rec[LG_REC_F4 * (size_t)id + 1], q2 = rec[LG_REC_F4 * (size_t)id + 2];
-            r0 = q0; r1 = q1;
-            r2 = make_float4(q2.x, __uint_as_float(e + 1u), __uint_as_float(lg_slot_of(tinfo[id], tx, ty)), 0.0f);
-        }
-    };
-    {
-        float4 r0, r1, r2;
-        fetch(0, r0, r1, r2);
-        stg[0][lane] = r0; stg[1][lane] = r1; stg[2][lane] = r2;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4 ca = make_float4(0, 0, 0, 0), cb = ca;     // this lane's entry: {x, y, ha, nb}, {hc, opacity, c0, c1}
-    float cc2 = 0.0f;
-    uint32_t crel = 0xFFFFFFFFu, cslot = 0xFFFFFFFFu;
-    float4 n0 = ca, n1 = ca, n2 = ca;                  // the bucket after next, between its load and its staging
-    float p[9];
-#pragma unroll
-    for (int v9 = 0; v9 < 9; v9++) p[v9] = 0.0f;
-    float T = 0.0f, Sd = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, Tfb = 0.0f, lastf = 0.0f, pxf = 0.0f, pyf = 0.0f;
-    const int span = nbk * 256;
-    const int steps = span + 63;
-    for (int t = 0; t < steps; t++) {
-        const int v = t - (int)lane;
-        // ---- a lane that has seen all 256 pixels of its entry writes the entry's row and takes the next bucket's entry ----
-        if (v >= 0 && v < span && (v & 255) == 0) {
-            if (cslot != 0xFFFFFFFFu) {
-                float4* dst = rows + 3 * (size_t)cslot;
-                dst[0] = make_float4(p[0], p[1], p[2], p[3]); dst[1] = make_float4(p[4], p[5], p[6], p[7]); dst[2] = make_float4(p[8], 0.0f, 0.0f, 0.0f);
-            }
-            ca = stg[0][lane]; cb = stg[1][lane];
-            const float4 r2 = stg[2][lane];
-            cc2 = r2.x; crel = __float_as_uint(r2.y); cslot = __float_as_uint(r2.z);
-#pragma unroll
-            for (int v9 = 0; v9 < 9; v9++) p[v9] = 0.0f;
-        }
-        // ---- wave-uniform: load the bucket after next once every lane has taken the staged one; stage it just before lane 0 needs it ----
-        const int ph = t & 255, bnext = (t >> 8) + 1;
-        if (ph == 64 && bnext < nbk) fetch(bnext, n0, n1, n2);
-        if (ph == 255 && bnext < nbk) {
-            stg[0][lane] = n0; stg[1][lane] = n1; stg[2][lane] = n2;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        // ---- the pixels move on by one lane; lane 0 takes pixel t mod 256 from the table (nothing while the pipeline drains) ----
-        const bool feed = t < span;
-        const float4 fa = pixA[ph], fb = pixB[ph];
-        const float2 fc = pixC[ph];
-        T = lg_march(fb.x, T); Sd = lg_march(fb.y, Sd);
-        lastf = lg_march(feed ? fb.z : 0.0f, lastf);
-        g0 = lg_march(fa.x, g0); g1 = lg_march(fa.y, g1); g2 = lg_march(fa.z, g2); Tfb = lg_march(fa.w, Tfb);
-        pxf = lg_march(fc.x, pxf); pyf = lg_march(fc.y, pyf);
-        (void)bwd_pair_fast(ca, cb, make_float4(cc2, 0.0f, 0.0f, 0.0f), crel <= __float_as_uint(lastf), pxf, pyf, T, Tfb, g0, g1, g2, Sd, p);
-        // ---- lane 63 is the last entry of the bucket (front-most): its pixel's {T, S} go back to the table for the next bucket ----
-        if (lane == 63u && v >= 0 && v < span) {
-            float2* dst = reinterpret_cast<float2*>(&pixB[v & 255]);
-            *dst = make_float2(T, Sd);
-        }
-    }
-    if (cslot != 0xFFFFFFFFu) {
-        float4* dst = rows + 3 * (size_t)cslot;
-        dst[0] = make_float4(p[0], p[1], p[2], p[3]); dst[1] = make_float4(p[4], p[5], p[6], p[7]); dst[2] = make_float4(p[8], 0.0f, 0.0f, 0.0f);
-    }
-}
+// (K7 with the splats on the lanes -- lg_blend_bwd_splat, round 5: EXPERIMENTS.md, "K7 structure")
 
 // diagnostics: K7's wave reduction (wave_reduce9_via_lds) on one wave (64 x 9 inputs -> 9 sums); used by tests/test_gpu_parity.py
 __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __restrict__ out)
@@ -1570,4 +1202,3 @@ __global__ void lg_debug_reduce9_kernel(const float* __restrict__ in, float* __r
     __syncthreads();
     if (threadIdx.x < 9) out[threadIdx.x] = dst[threadIdx.x * LG_Q];
 }
-

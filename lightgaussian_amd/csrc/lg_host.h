@@ -160,10 +160,8 @@ static ImgView carve_img(void* base, int W, int H)
 // tile becomes ten independent work items instead of one 4 ms serial chain.  Tiles with at most one segment never
 // touch the checkpoints.  S is part of the VIEW (the caller passes the same lg_view to the
 // forward and to its backward; the forward also stores it in meta[2] and the backward kernels refuse to run on a mismatch):
-// the library keeps no state of its own.  512 by measurement (round 3; 1024 in round 2, when the forward walked long lists only
-// serially): fwd+bwd views/s at S = 1024 / 768 / 512 -- uniform benchmark scene 555 / 555 / 555, heavy-tailed scene 439 / 456 / 467, 6 M
-// Gaussians at 1600x1060 352 / 356 / 359, 3x larger splats 435 / 424 / 430.  In a dense pile every entry touches all four 8x8
-// blocks of the tile: a 2048-entry segment alone took 0.8 ms.  64 / 128 exercise the machinery on small scenes (tests).
+// the library keeps no state of its own.  512 by measurement (the sweep over S and scenes: EXPERIMENTS.md, "segment length");
+// 64 / 128 exercise the machinery on small scenes (tests).
 #define LG_DEFAULT_SEGMENT 512
 static inline int lg_segment_of(const lg_view* v) { return v->segment_length > 0 ? v->segment_length : LG_DEFAULT_SEGMENT; }
 

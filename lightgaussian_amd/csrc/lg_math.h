@@ -95,8 +95,6 @@ LG_HD float lg_seqsum32(float w, uint32_t c)
         uint32_t inc = ud - ub;                                    // steady increment in ulps
         if (inc == 0) return s;
         uint32_t top = (e << 23) | 0x7FFFFFu;                      // largest value of this binade
-        // (round 5, measured: a reciprocal estimate + exact correction instead of this integer division changes nothing -- lg_score_kernel
-        //  41.3 -> 44.5 us at C3, box noise: the kernel's time is the divergent walk over the binades, not the division)
         uint32_t room = (top - ud) / inc;                          // steps that stay inside it
         uint32_t k = room < c ? room : c;
         s = lg_bits2f(ud + k * inc);

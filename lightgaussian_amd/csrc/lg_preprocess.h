@@ -116,13 +116,7 @@ lg_preprocess(int N, int M, int D, int W, int H, float tanfovx, float tanfovy, f
     LgSplat sp;
     if (i < N) {
         px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2];
-        // near-plane test first so culled Gaussians cost 12 bytes of reads (hoisting the scale / rotation / opacity loads
-        // above this branch was measured twice -- round 2 at 20 waves per CU, round 4 at 12: no change).
-        // (round 4, measured and rejected: requesting the SH row together with these loads for every splat whose centre projects onto
-        //  the screen grown by 16 pixels -- two dependent round trips per wave instead of three, the late read kept for splats that turn
-        //  out visible without having passed the test: 0.1945 -> 0.187 ms, gradients and images unchanged; 4 % of K1 for a second load
-        //  path.  What the ablations say K1 spends its time on: without the SH reads 0.104 ms, without the record / Jacobian stores
-        //  0.178, without both 0.091 (at 20 waves per CU, where the whole kernel took 0.221).)
+        // near-plane test first so culled Gaussians cost 12 bytes of reads (hoisted loads, an early SH request: EXPERIMENTS.md, "K1 / K9")
         const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
         if (vz > 0.2f) {
             if (cov3D_precomp) {

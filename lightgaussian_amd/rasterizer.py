@@ -46,7 +46,7 @@ _OPTIONS = {"weight_policy": _lib.WEIGHT_OPACITY, "fast_exp": True, "profile": F
             "fuse_getters": True, "sync_free": "validated", "max_depth": 100.0, "capacity_margin": 1.25,
             "segment_length": 0, "long_tiles": "auto", "count_long_tiles": "serial",
             # cross-check switches of the tests: never needed in production, never read from the environment
-            "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "bwd_splat_parallel": False, "count_wide_band": False}
+            "sh_jacobian": True, "narrow_key": False, "sort_all_bits": False, "k1_lds": False, "count_wide_band": False}
 _PER_CALL_ONLY = ("pending", "tag", "status_override", "differentiated", "sh_grad_sink", "score_out", "count_sum")
 _LONG_TILES = ("serial", "auto", "parallel")
 _tls = threading.local()
@@ -121,7 +121,6 @@ def set_option(name, value):
               count_sum = a contiguous int32 [N] device tensor to which the view's gaussians_count is ADDED by the kernel that writes the
               score (lg_view.count_sum; not atomic: one view at a time per accumulator).  Together they are prune_list's
               `gaussian_list += ...; imp_list += ...` bookkeeping (prune.py:144-155) without a torch launch per view (prune_list_sharded);
-    bwd_splat_parallel: the backward blend on the other parallel axis (round-5 prototype lg_blend_bwd_splat, DESIGN 22.1);
     count_wide_band: tests only -- LG_FLAG_COUNT_WIDE_BAND (the parallel long-tile count walk sends many more pixels through its exact fix-up);
     sh_jacobian / narrow_key / sort_all_bits / k1_lds: cross-check switches for the tests (K9 re-reads the SH coefficients instead
               of K1's saved direction Jacobian; the sort key laid out as if 40 bits were available; every key bit through the
@@ -274,8 +273,6 @@ class _Call:
             flags |= _lib.FLAG_SORT_ALL_BITS
         if opts["k1_lds"]:
             flags |= _lib.FLAG_K1_LDS
-        if opts["bwd_splat_parallel"]:
-            flags |= _lib.FLAG_BWD_SPLAT_PARALLEL
         if opts["count_wide_band"]:
             flags |= _lib.FLAG_COUNT_WIDE_BAND
         self.view = _lib.lg_view(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),

@@ -4,9 +4,7 @@
       parallel.RankOneSHExchange): the coefficient gradients rebuilt from dL/d(rgb) and the camera centre are the SAME BITS K9 writes
       for that view, every other gradient of the view is untouched, two views summed in view order equal autograd's accumulation,
       and the exchange object run through RCCL at world size 1 (collectives forced) returns the local result.
-  (b) lg_blend_bwd_splat (LG_FLAG_BWD_SPLAT_PARALLEL: K7 on the other parallel axis -- lane = list entry, pixel state marching
-      through the wave): the gradients of lg_blend_bwd up to float rounding, deterministic run to run, with one-segment lists,
-      multi-segment lists (checkpoints), partial buckets and empty tiles; within the oracle tolerance of test_gpu_parity.
+  (b) (round 5's prototype of K7 on the other parallel axis, lg_blend_bwd_splat, was removed in round 6: EXPERIMENTS.md, "K7 structure")
   (c) the pair step of the forward blend on scalar lane masks (fwd_pair_m): covered by every bit-parity test of the suite (counts,
       scores, canonical images are compared with the oracle bit for bit); here only the long-tile rewalk, which shares it."""
 import math
@@ -189,43 +187,6 @@ def _grads(g, cam, W, H, bg, gimg, options, fused=True):
     out = {n: getattr(pc, n).grad.detach().cpu().numpy() for n in RAW}
     out["means2D"] = pkg["viewspace_points"].grad.detach().cpu().numpy()
     return out
-
-
-@pytest.mark.parametrize("case", ["uniform", "segments64", "dense_pile", "tiny"])
-def test_splat_parallel_backward_gives_the_gradients_of_the_pixel_parallel_one(case):
-    dev = torch.device(DEV)
-    cfg = {"uniform": dict(N=6000, W=208, H=144, scale=0.03, opm=0.0, seg=0),
-           "segments64": dict(N=9000, W=160, H=96, scale=0.05, opm=-1.0, seg=64),        # every list of > 64 entries in several segments
-           "dense_pile": dict(N=5000, W=96, H=64, scale=0.12, opm=1.5, seg=128),         # saturating pixels, lists of thousands
-           "tiny": dict(N=70, W=40, H=24, scale=0.05, opm=0.0, seg=0)}[case]              # partial buckets, empty tiles, image edge
-    g = _scene(N=cfg["N"], seed=17, scale=cfg["scale"], opm=cfg["opm"])
-    W, H = cfg["W"], cfg["H"]
-    cam = syn.orbit_camera(2, 7, W, H, radius=5.0)
-    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
-    gimg = torch.from_numpy(np.random.RandomState(11).randn(3, H, W).astype(np.float32)).to(dev)
-    base = {"segment_length": cfg["seg"]}
-    a = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=False))
-    b = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=True))
-    b2 = _grads(g, cam, W, H, bg, gimg, dict(base, bwd_splat_parallel=True))
-    for n in a:
-        assert np.isfinite(b[n]).all(), n
-        assert np.array_equal(b[n], b2[n]), f"{n}: the splat-parallel backward is not deterministic run to run"
-        scale = np.abs(a[n]).max() + 1e-30
-        assert np.abs(a[n] - b[n]).max() <= 2e-5 * scale, f"{case} {n}: {np.abs(a[n] - b[n]).max() / scale:.3e} of the tensor's scale"
-    assert np.abs(a["_xyz"]).max() > 0
-    # and against the float64 oracle, with the tolerance rule of test_gpu_parity (literal getters: the oracle takes activated tensors)
-    if case in ("uniform", "tiny"):
-        kw = common.scene_kwargs(g, cam, W, H, deg=3, bg=(0.3, 0.2, 0.1), as_torch=True)
-        kwn = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in kw.items()}
-        f64 = oracle.forward(dtype=np.float64, **kwn); g64 = oracle.backward(f64, gimg.cpu().numpy())
-        f32 = oracle.forward(**kwn); g32 = oracle.backward(f32, gimg.cpu().numpy())
-        from lightgaussian_amd import rasterizer
-        with rasterizer.options(bwd_splat_parallel=True, segment_length=cfg["seg"]):
-            hip = gpu_common.hip_forward_backward(kw, grad_image=gimg.cpu().numpy())["grads"]
-        for name, gv in hip.items():
-            floor = gpu_common.rel_err(g32[name], g64[name])
-            err = gpu_common.rel_err(np.asarray(gv).reshape(np.shape(g64[name])), g64[name])
-            assert err <= max(1e-4, 3.0 * floor), f"{case} {name}: {err:.3e} (fp32 oracle floor {floor:.3e})"
 
 
 # ---- (d) parallel long-tile walk of the significance-only pass (lg_count_seg / _rewalk / _fixup) ---------------------------------------
