@@ -155,7 +155,7 @@ def count_pass(kw, options):
     return cnt.cpu().numpy(), score.cpu().numpy(), meta.cpu().numpy().view(np.uint32)
 
 
-bad3 = par_items = fixups = 0
+bad3 = par_items = fixups = n4 = 0
 n3 = 0 if __name__ != "__main__" else int(os.environ.get("LG_FUZZ_N3", trials // 2))
 for t in range(first, first + n3):
     kw, npk, meta, rs = make_trial(t)
@@ -171,10 +171,20 @@ for t in range(first, first + n3):
                 par_items += int(ran); fixups += int(m[5]) if ran else 0
             if not np.array_equal(c, ref.count): why.append(f"{tag}:count({int((c != ref.count).sum())})")
             if not np.array_equal(sc.view(np.uint32), ref.score.view(np.uint32)): why.append(f"{tag}:score")
+        # round 6: the per-hit weight policies (Q24.40 sums, one packed atomic per (wave, entry) into per-instance slots): counts and scores
+        # against the oracle's sequential loop, bit for bit, and a second run of the same view against the first (no float atomics)
+        for pol, opol in (("alpha", oracle.W_ALPHA), ("alpha_t", oracle.W_ALPHA_T)):
+            rp = oracle.forward(count=True, weight_policy=opol, **npk)
+            c, sc, _m = count_pass(kw, dict(weight_policy=pol, segment_length=S))
+            c2, sc2, _m = count_pass(kw, dict(weight_policy=pol, segment_length=S))
+            n4 += 1
+            if not np.array_equal(c, rp.count): why.append(f"{pol}:count({int((c != rp.count).sum())})")
+            if not np.array_equal(sc.view(np.uint32), rp.score.view(np.uint32)): why.append(f"{pol}:score({int((sc.view(np.uint32) != rp.score.view(np.uint32)).sum())})")
+            if not (np.array_equal(c, c2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))): why.append(f"{pol}:run-to-run")
     if why:
         bad3 += 1
         print(f"COUNT MISMATCH trial {t}: N={meta['N']} {meta['W']}x{meta['H']} S={S} wide={wide}: {', '.join(why)}")
 if __name__ == "__main__":
     print(f"fuzz: trials {first}..{first + trials - 1}, {bad} mismatches; fused-getter phase: {n2} trials, {bad2} mismatches; "
-          f"significance-only phase: {n3} trials ({par_items} with multi-segment lists in the parallel walk, {fixups} exact fix-ups), {bad3} mismatches")
+          f"significance-only phase: {n3} trials ({par_items} with multi-segment lists in the parallel walk, {fixups} exact fix-ups; {n4} per-hit-weight renders), {bad3} mismatches")
     sys.exit(1 if bad + bad2 + bad3 else 0)

@@ -6,13 +6,16 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 run() { timeout -s KILL 600 python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
 import sys, json
 d=json.loads(sys.stdin.read().strip()); c=d['config']; print('$*', '->', d['value'], 'views/s', d['ms_per_step'], 'ms', 'burst', (d.get('contract_region') or {}).get('views_per_s'), 'V', c['visible_gaussians'], 'R', c['tile_instances'], d.get('kernels_ms'), 'batch3', (d.get('camera_batch_3') or {}), (d.get('significance_pass') or {}), (d.get('literal_getter_pattern') or {}))" | cut -c1-1800; }
-timeout -s KILL 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15 > gpurun_out/round_pytest.log; grep -E "passed|failed" gpurun_out/round_pytest.log | tail -1; grep -E "^FAILED|^E  " gpurun_out/round_pytest.log | cut -c1-300 | head
+timeout -s KILL 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15 > gpurun_out/round_pytest.log; grep -E "passed|failed" gpurun_out/round_pytest.log | tail -1; grep -E "^FAILED|^E  " gpurun_out/round_pytest.log | cut -c1-300 | head
 timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 ( time timeout -s KILL 900 python bench.py ) > gpurun_out/round_bench_default.log 2>&1; tail -5 gpurun_out/round_bench_default.log | cut -c1-7000
 run --n-gaussians 1000000 --mode fwd --steps 100 --no-literal
 run --n-gaussians 3000000 --mode fwd --steps 100 --no-literal
 run --n-gaussians 3000000 --mode count --steps 100
+run --n-gaussians 3000000 --mode count --steps 100 --weight-policy alpha_t
+run --n-gaussians 3000000 --mode count --steps 100 --weight-policy alpha
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy
+run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --weight-policy alpha_t
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1
 run --n-gaussians 3000000 --mode count --steps 100 --scene heavy --count-streams 1 --count-long-tiles parallel --segment-length 2048
 run --n-gaussians 3000000 --mode count --steps 100 --scale 0.0045
