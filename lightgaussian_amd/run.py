@@ -8,6 +8,10 @@
          from its own shard of the train list, gradients are averaged over the ranks in front of every optimizer.step() (rows no
          rank saw are not exchanged), add_densification_stats / max_radii2D are reduced, prune_list is sharded by camera, ranks
          other than 0 write under <model_path>/.rank<r>)
+    python -m lightgaussian_amd.run --weight-policy=alpha_t /path/to/prune_finetune.py ...
+        (what one (pixel, Gaussian) hit adds to important_score in every count_render of the run: opacity (default, the paper's sigma_j),
+         one, alpha or alpha_t -- the weight of the reference's un-vendored fork is not verifiable from its repository, SURVEY section 2.2;
+         all four are deterministic and bit-pinned)
     python -m lightgaussian_amd.run --fused-adam /path/to/prune_finetune.py ...
         (opt-in, outside the replaced path: torch.optim.Adam as the trainers construct it, but with fused=True -- fused_adam() below)
     python -m lightgaussian_amd.run --lazy-loss /path/to/prune_finetune.py ...
@@ -344,6 +348,7 @@ def main(argv=None):
     distributed = no_patch = verbose = adam = lazy = no_timing = False
     backend = "nccl"
     dp_overlap = False
+    weight_policy = None
     while argv and argv[0].startswith("--") and not argv[0].endswith(".py"):
         flag = argv.pop(0)
         if flag == "--distributed":
@@ -360,10 +365,14 @@ def main(argv=None):
             lazy = True
         elif flag == "--no-iter-timing":
             lazy = no_timing = True
+        elif flag.startswith("--weight-policy="):
+            from . import rasterizer
+            weight_policy = flag.split("=", 1)[1]
+            rasterizer.weight_policy_id(weight_policy)          # (raises on an unknown name before anything is set up)
         elif flag.startswith("--backend="):       # gloo: CPU tests of the launcher with a stand-in trainer (the rasterizer has no CPU path)
             backend = flag.split("=", 1)[1]
         else:
-            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --dp-overlap --no-patch --verbose --fused-adam --lazy-loss --no-iter-timing, then the script and ITS arguments)")
+            raise SystemExit(f"lightgaussian_amd.run: unknown option {flag} (options: --distributed --dp-overlap --no-patch --verbose --fused-adam --lazy-loss --no-iter-timing --weight-policy=NAME, then the script and ITS arguments)")
     if not argv:
         raise SystemExit(__doc__)
     script = os.path.abspath(argv[0])
@@ -403,6 +412,9 @@ def main(argv=None):
         dp.config_from_env()
         if dp_overlap:
             dp.configure(overlap=True)
+    if weight_policy is not None:
+        from . import rasterizer
+        rasterizer.set_option("weight_policy", rasterizer.weight_policy_id(weight_policy))     # process default of every count_render of the run
     if adam:
         fused_adam(True)
     if lazy:

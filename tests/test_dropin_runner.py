@@ -113,6 +113,14 @@ def test_runner_command_line_sets_up_the_path_like_python_does(tmp_path, monkeyp
     assert rec["shim"].startswith(dropin_common.ROOT)
     bad = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--frobnicate", str(script)], capture_output=True, text=True, cwd=dropin_common.ROOT)
     assert bad.returncode != 0 and "unknown option" in bad.stderr
+    # --weight-policy=NAME: the process default of every count_render of the run (round 6); an unknown name is refused before the script runs
+    script.write_text("import json\nfrom lightgaussian_amd import rasterizer, _lib\nprint(json.dumps({'wp': rasterizer.resolve_options()['weight_policy'], 'alpha_t': _lib.WEIGHT_ALPHA_T}))\n")
+    out = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--no-patch", "--weight-policy=alpha_t", str(script)],
+                         capture_output=True, text=True, cwd=dropin_common.ROOT, check=True).stdout.strip().splitlines()[-1]
+    rec = json.loads(out)
+    assert rec["wp"] == rec["alpha_t"]
+    bad = subprocess.run([sys.executable, "-m", "lightgaussian_amd.run", "--weight-policy=alphaT", str(script)], capture_output=True, text=True, cwd=dropin_common.ROOT)
+    assert bad.returncode != 0 and "weight_policy" in bad.stderr
 
 
 def test_runner_rebinds_what_the_trainer_script_then_imports_by_name(tmp_path):
