@@ -80,6 +80,26 @@ int main()
     double mean = 0; for (float c : h_color) mean += c; mean /= h_color.size();
     printf("lg_forward_count: abi %d, %lld tile instances, %lld pixel hits, mean colour %.6f\n", lg_abi_version(), (long long)R, hits, mean);
 
+    // ABI 7: the running hit count (lg_view.count_sum) and a per-hit weight policy (exact Q24.40 sums: two runs give the same bits).
+    // Two more count forwards into a zeroed accumulator: it must hold twice the per-view counts; the ALPHA_T scores of both runs are equal
+    int32_t* csum = nullptr; float *score_a = nullptr, *score_b = nullptr;
+    HIPCHECK(hipMalloc((void**)&csum, N * 4)); HIPCHECK(hipMemset(csum, 0, N * 4));
+    HIPCHECK(hipMalloc((void**)&score_a, N * 4)); HIPCHECK(hipMalloc((void**)&score_b, N * 4));
+    lg_view va = v; va.count_sum = csum;
+    LGCHECK(lg_forward_count(&va, &g, geom, img, alloc_cb, nullptr, LG_WEIGHT_ALPHA_T, color, radii, count, score_a, &bin, &R, stream));
+    LGCHECK(lg_forward_count(&va, &g, geom, img, alloc_cb, nullptr, LG_WEIGHT_ALPHA_T, color, radii, count, score_b, &bin, &R, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    std::vector<int32_t> h_csum(N), h_cnt2(N); std::vector<float> h_sa(N), h_sb(N);
+    HIPCHECK(hipMemcpy(h_csum.data(), csum, N * 4, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(h_cnt2.data(), count, N * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(h_sa.data(), score_a, N * 4, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(h_sb.data(), score_b, N * 4, hipMemcpyDeviceToHost));
+    double wsum = 0; int same = 1;
+    for (int i = 0; i < N; i++) {
+        same &= (h_csum[i] == 2 * h_count[i]) && (h_cnt2[i] == h_count[i]) && (memcmp(&h_sa[i], &h_sb[i], 4) == 0) && ((h_count[i] == 0) == (h_sa[i] == 0.0f));
+        wsum += h_sa[i];
+    }
+    printf("count_sum + LG_WEIGHT_ALPHA_T: running count = 2 x per-view count and scores reproducible: %s; sum of alpha T weights %.6f\n", same ? "yes" : "NO", wsum);
+    if (!same || !(wsum > 0)) { fprintf(stderr, "unexpected result\n"); return 1; }
+
     // backward of sum(color) through a plain render
     LGCHECK(lg_forward(&v, &g, geom, img, alloc_cb, nullptr, color, radii, &bin, &R, stream));
     std::vector<float> ones(3 * W * H, 1.0f); float* dL = dev(ones);

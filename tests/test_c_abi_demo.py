@@ -1,6 +1,7 @@
 """-m gpu: the C ABI used from a plain C++ host program (no Python, no PyTorch): examples/c_abi_demo.cpp is compiled with
-hipcc against include/lightgaussian.h + liblightgaussian_hip.so and run; it renders (count variant), runs the backward and
-exercises the invalid-argument path."""
+hipcc against include/lightgaussian.h + liblightgaussian_hip.so and run; it renders (count variant), accumulates a running hit count
+through lg_view.count_sum with the ALPHA_T weight policy (scores reproducible bit for bit), runs the backward and exercises the
+invalid-argument path."""
 import os
 import shutil
 import subprocess
@@ -20,3 +21,4 @@ def test_c_abi_demo_builds_and_runs(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C ABI demo OK" in out.stdout and "provide excatly one of either SHs or precomputed colors" in out.stdout
+    assert "running count = 2 x per-view count and scores reproducible: yes" in out.stdout          # ABI 7: lg_view.count_sum, LG_WEIGHT_ALPHA_T

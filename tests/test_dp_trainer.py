@@ -212,6 +212,16 @@ def test_two_ranks_train_one_model_equal_to_one_process_averaging_the_same_views
         assert np.array_equal(o["radii"], np.maximum(idx, 5 - idx).astype(np.float32))
 
 
+def test_replica_digest_sees_one_changed_element_and_is_a_device_side_reduction():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 3, generator=g)
+    y = x.clone(); y[437, 1] = torch.nextafter(y[437, 1], torch.tensor(10.0))       # one ulp in one coordinate
+    a, b = dp.replica_digest(x), dp.replica_digest(y)
+    assert a.dtype == torch.int64 and a.dim() == 0 and int(a) == int(dp.replica_digest(x.clone())) and int(a) != int(b)
+    assert int(dp.replica_digest(x[:0])) == 0
+    assert int(dp.replica_digest(x.t().contiguous().t())) == int(a)                  # values, not strides
+
+
 def test_shards_cover_every_camera_once_and_degenerate_cases():
     cams = list(range(10))
     assert sorted(sum((dp.shard_cameras(cams, r, 4) for r in range(4)), [])) == cams

@@ -150,3 +150,35 @@ def test_images_beyond_the_q24_40_range_are_refused_for_per_hit_weights():
             gpu_common.hip_forward_backward(kw, count=True)
     out = gpu_common.hip_forward_backward(kw, count=True)
     assert out["count"].sum() > 0
+
+
+def test_score_out_and_count_sum_options_write_where_the_caller_says():
+    """The fused epilogue of the significance pass (lg_view.count_sum, rasterizer options score_out / count_sum): the forward writes
+    important_score INTO the caller's row and ADDS the view's hit count to the caller's running sum -- the `gaussian_list += ...;
+    imp_list += ...` bookkeeping of prune.py:144-155 without a launch of its own.  Equal to the plain outputs for the integer and the
+    per-hit policies; wrong shapes / dtypes are refused."""
+    from lightgaussian_amd import rasterizer
+    from lightgaussian_amd.gaussian_renderer import count_render
+    dev = torch.device("cuda:0")
+    N, W, H = 5000, 192, 128
+    pc = syn.make_gaussians(N, seed=3, log_scale_mean=math.log(0.03)).to(dev)
+    cams = [syn.orbit_camera(k, 5, W, H, radius=5.0).to(dev) for k in range(3)]
+    bg, pipe = torch.zeros(3, device=dev), syn.PipelineParams()
+    for pol in ("opacity", "alpha_t"):
+        rows = torch.full((3, N + 7), -1.0, device=dev)               # (a wider matrix: the row slice is what the forward gets)
+        running = torch.zeros(N, dtype=torch.int32, device=dev)
+        plain_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            for k, cam in enumerate(cams):
+                ref = count_render(cam, pc, pipe, bg, options={"weight_policy": pol, "skip_color_in_count": True})
+                plain_cnt += ref["gaussians_count"]
+                out = count_render(cam, pc, pipe, bg, options={"weight_policy": pol, "skip_color_in_count": True,
+                                                               "score_out": rows[k, :N], "count_sum": running})
+                assert out["important_score"].data_ptr() == rows[k].data_ptr()
+                assert torch.equal(out["gaussians_count"], ref["gaussians_count"])
+                assert torch.equal(rows[k, :N].view(torch.int32), ref["important_score"].view(torch.int32))
+        assert torch.equal(running, plain_cnt) and bool((rows[:, N:] == -1.0).all())
+    with pytest.raises(ValueError):
+        count_render(cams[0], pc, pipe, bg, options={"score_out": torch.zeros(N + 1, device=dev)})
+    with pytest.raises(ValueError):
+        count_render(cams[0], pc, pipe, bg, options={"count_sum": torch.zeros(N, dtype=torch.int64, device=dev)})

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Fuzz trials beyond the round script's 0..149 (tools/gpu_fuzz.py, LG_FUZZ_FIRST), under the variant switches the library has:
 # segmented backward with 64-entry segments, long-tile walks serial / parallel (colour forward AND the significance pass's
-# parallel walk), the host-synchronous forward, 40-bit keys.  Usage: gpu_fuzz_campaign.sh [K] [FIRST].  Log: gpurun_out/r05_fuzz_campaign[_from_FIRST].log
+# parallel walk), the host-synchronous forward, 40-bit keys.  Usage: gpu_fuzz_campaign.sh [K] [FIRST].  Log: gpurun_out/r06_fuzz_campaign[_from_FIRST].log
 mkdir -p gpurun_out
-L=gpurun_out/r05_fuzz_campaign${2:+_from_$2}.log
+L=gpurun_out/r06_fuzz_campaign${2:+_from_$2}.log
 : > $L
 run() { echo "== $*" >> $L; ( time env "$@" ) >> $L 2>&1; }
 K=${1:-1}        # scale: K = 1 is ~1 minute of GPU time (a trial takes ~70 ms), K = 15 ~12 minutes
