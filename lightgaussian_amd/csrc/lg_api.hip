@@ -210,12 +210,15 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
             ProfScope ps(prof, "preprocess", stream);
             // K1 runs faster with FEWER waves in flight where it reads SH rows: unused dynamic LDS caps it at 12 waves per CU there (the sweep,
             // K9's opposite behaviour and the significance pass's A/B: EXPERIMENTS.md, "K1 / K9")
+            // (the count / score accumulators are cleared here for the integer weights; the per-hit policies accumulate in the slots and
+            //  lg_score_slots writes both outputs)
+            int32_t* const k1_zero_count = (count && weight_policy >= LG_WEIGHT_ALPHA) ? nullptr : out_count;
             const size_t k1_dyn = (g->shs && !g->colors_precomp && !(v->flags & LG_FLAG_SKIP_COLOR)) ? LG_K1_PAD_LDS : 0;
 #define LAUNCH_PP(RAWP, DIR)                                                                                                         \
     lg_preprocess<RAWP, DIR><<<nblk, LG_PP, (DIR) ? k1_dyn : 0, stream>>>(N, g->M, v->sh_degree, W, H, v->tanfovx, v->tanfovy,                          \
                                                                       v->scale_modifier, v->prefiltered, (v->flags & LG_FLAG_SKIP_COLOR) ? 1 : 0, v->viewmatrix, v->projmatrix, \
                                                                       v->campos, g->means3D, g->shs, g->shs_rest, g->colors_precomp,   \
-                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, out_count, out_score, \
+                                                                      g->opacities, g->scales, g->rotations, g->cov3D_precomp, geo, out_radii, k1_zero_count, out_score, \
                                                                       k1_clear, k1_nclear, (v->flags & LG_FLAG_SAVE_SH_JACOBIAN) ? 1 : 0)
             // SH rows are read directly by their lanes (dword-aligned dwordx4 loads); LG_K1_LDS=1 selects the LDS-staged reads
             const bool direct = !(v->flags & LG_FLAG_K1_LDS);
@@ -341,7 +344,8 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         // per-hit weights (ALPHA / ALPHA_T): the kernel is instantiated per policy and adds {count | Q8.40 weight} words into the instances'
         // pre-sort slots -- the radix sort's input buffer, free since lg_tile_sort and cleared here
         const int fs = !count ? 0 : weight_policy == LG_WEIGHT_ALPHA ? 2 : weight_policy == LG_WEIGHT_ALPHA_T ? 3 : 0;
-        if (fs && cap > 0 && N > 0) HIP_TRY(lg_zero_async(bin.keys_in, (size_t)cap * 8, stream));
+        // (the significance-only variant writes every slot exactly once -- its waves merge in LDS -- and needs no clear)
+        if (fs && cap > 0 && N > 0 && !(!fast && (v->flags & LG_FLAG_SKIP_COLOR))) HIP_TRY(lg_zero_async(bin.keys_in, (size_t)cap * 8, stream));
         const bool nocolor = count && !fast && (v->flags & LG_FLAG_SKIP_COLOR);   // significance-only pass: no colour, no per-pixel outputs
         if (!count) { if (fast) LAUNCH_FWD(false, 0, false, true); else LAUNCH_FWD(false, 0, true, true); }
         else if (nocolor) {
@@ -381,7 +385,7 @@ static int forward_impl(const lg_view* v, const lg_gaussians* g, void* geom_p, v
         if (weight_policy == LG_WEIGHT_ONE || weight_policy == LG_WEIGHT_OPACITY)
             lg_score_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, out_count, weight_policy == LG_WEIGHT_OPACITY ? g->opacities : nullptr, out_score, v->count_sum);
         else
-            lg_score_slots<<<(N + 255) / 256, 256, 0, stream>>>(N, geo.touched, geo.tinfo, (const unsigned long long*)bin.keys_in, (uint32_t)cap, out_count, out_score, v->count_sum);
+            lg_score_slots<<<(N + 255) / 256, 256, 0, stream>>>(N, geo.touched, geo.offsets, (const unsigned long long*)bin.keys_in, (uint32_t)cap, out_count, out_score, v->count_sum, geo.counters);
         KCHECK("lg_score_kernel");
     }
     if (debug && N > 0) {

@@ -124,17 +124,26 @@ __device__ __forceinline__ uint64_t fwd_pair_m(const float4& a, const float4& b,
 // readlane), and no cross-lane traffic in the pair step itself.  Lane 8 r + c keeps the total of chunk c: lane l ends up owning compacted
 // entry 8 (l & 7) + (l >> 3) of the batch (LG_WQ_OWNER) -- its hit count (ballot popcount of the pair step) AND its weight total.
 //
-// Where the totals go (round 6, measured -- tools/ubench/atomic_rate.hip, profiles/r06_call_b.log): a random-address global atomic costs the
-// device ~40 ns of its atomic pipe whatever its width (4.8 M per view = 0.19 ms: hidden behind the 0.3 ms of arithmetic when there is ONE
-// per (wave, entry), as in the integer-weight variant; a second one per (wave, entry) -- count[id] and a 64-bit sum[id] -- made the kernel
-// atomic-bound, 0.33 -> 0.61 ms).  So count and weight total travel in ONE 64-bit atomic: per (tile, Gaussian) INSTANCE the ranges are
-// small -- at most 256 hits, weight below 256 -- and {count : 16 | Q8.40 : 48} fits a word.  The word lives at the instance's pre-sort slot
-// (lg_slot_of: a closed form of the Gaussian's tile rectangle; the radix sort's input buffer, free by now and cleared, holds the slots) and
-// lg_score_slots sums every Gaussian's consecutive slots into out_count / out_score -- no atomics there.
+// Where the totals go (round 6, measured -- tools/ubench/atomic_rate.hip, profiles/r06_call_b.log, EXPERIMENTS.md Part II section 1): a
+// random-address global atomic costs the device ~40 ns of its atomic pipe whatever its width (4.8 M per view = 0.19 ms: hidden behind the
+// 0.3 ms of arithmetic when there is ONE per (wave, entry), as in the integer-weight variant; a second one per (wave, entry) -- count[id] and a
+// 64-bit sum[id] -- made the kernel atomic-bound, 0.33 -> 0.61 ms).  So count and weight total travel in ONE 64-bit word: per (tile,
+// Gaussian) INSTANCE the ranges are small -- at most 256 hits, weight below 256 -- and {count : 16 | Q8.40 : 48} fits.  The word lives at the
+// instance's pre-sort slot (lg_slot_of: a closed form of the Gaussian's tile rectangle; the radix sort's input buffer, free by now, holds the
+// slots) and lg_score_slots sums every Gaussian's consecutive slots into out_count / out_score -- no atomics there.
+//   * significance-only pass (no colour: the variant the prune pass runs): the four waves of a tile MERGE in LDS first -- a ring of
+//     LG_TM_SLOTS batch accumulators (ds_add_u64 per (wave, entry)), an arrival counter per batch, and the last wave to leave a batch
+//     writes its 64 words with plain stores (tile_leave in lg_blend_fwd).  One store per instance, zeros included: no global atomic, no
+//     clear of the slots, one binning-record gather per (tile, entry) instead of one per (wave, entry).  0.440 -> 0.400 ms, 1352 -> 1448 views/s.
+//     The waves stay autonomous: nobody waits at a batch except for a ring slot whose flush is still in progress.
+//   * count forwards that also return the image: one atomic per (wave, entry) into the cleared slots.
 #define LG_WQ_ROWS 8
 #define LG_WQ_STRIDE 68                               // row stride in floats (64 lanes + 16 bytes of skew)
 #define LG_WQ_OWNER(lane) (8u * ((lane) & 7u) + ((lane) >> 3))
 #define LG_SLOT_COUNT_SHIFT 48
+#ifndef LG_TM_SLOTS
+#define LG_TM_SLOTS 4
+#endif                                                // batches of a tile that may be "open" at once (waves of a tile drift apart by at most this many)
 __device__ __forceinline__ uint64_t lg_wq_rowsum(const float* wq, uint32_t lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -170,6 +179,13 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     static_assert(FSCORE == 0 || ((FSCORE == LG_W_ALPHA || FSCORE == LG_W_ALPHA_T) && COUNT), "FSCORE is 0 or a per-hit weight policy of the count variant");
     __shared__ float4 q0[4][LG_Q], q1[4][LG_Q], q2[4][LG_Q];
     __shared__ __attribute__((aligned(16))) float wq[FSCORE ? 4 : 1][FSCORE ? LG_WQ_ROWS * LG_WQ_STRIDE : 1];
+    // Significance-only pass with per-hit weights (MERGE): the four waves of a tile add their per-entry {count | weight} words into a ring of
+    // LG_TM_SLOTS batch accumulators in LDS; whichever wave is the LAST to pass a batch writes the batch's 64 words to the instances' slots
+    // with plain stores -- one store per (tile, Gaussian) instance, zeros included, so the slots need neither atomics nor a clear.
+    constexpr bool MERGE = FSCORE != 0 && !COLOR;
+    __shared__ unsigned long long tacc[MERGE ? LG_TM_SLOTS : 1][MERGE ? LG_Q : 1];
+    __shared__ uint32_t tarr[MERGE ? LG_TM_SLOTS : 1];      // waves that have passed the batch in the slot
+    __shared__ uint32_t tgen[MERGE ? LG_TM_SLOTS : 1];      // flushes the slot has seen: batch b may use slot b % LG_TM_SLOTS once tgen == b / LG_TM_SLOTS
     // lists longer than par_min (when non-zero) are left to the parallel long-tile kernels below: a pure function of this
     // view's own numbers (counters[3] = its instance count), evaluated identically by every workgroup
     const uint32_t par_min = lg_par_min(long_mode, S, counters[3], ntiles);
@@ -204,6 +220,38 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // lists longer than par_min (when set): their segments are walked in parallel by lg_blend_fwd_seg / _scan / _rewalk (below) --
     // or, in the significance-only pass (no colour: par_min is only non-zero there for the integer weights), by lg_count_seg / _rewalk / _fixup
     if ((longt || !COLOR) && par_min != 0u && (range.y - range.x) > par_min) return;
+    if (MERGE) {
+        for (uint32_t i = threadIdx.x; i < LG_TM_SLOTS * LG_Q; i += 256u) (&tacc[0][0])[i] = 0ull;
+        if (threadIdx.x < LG_TM_SLOTS) { tarr[threadIdx.x] = 0u; tgen[threadIdx.x] = 0u; }
+        __syncthreads();
+    }
+    // MERGE: batch `bi` of the tile is left behind by this wave -- wait until its ring slot is free (the flush of batch bi - LG_TM_SLOTS has
+    // happened: every wave passed that batch long ago, so the wait is for a flush in progress at most), add what `add()` has, then arrive; the
+    // fourth wave to arrive owns the flush.  A wave that stops early (all its pixels saturated) still arrives at every remaining batch.
+    auto tile_leave = [&](uint32_t bi, auto add) {
+        const uint32_t ts = bi % LG_TM_SLOTS, want = bi / LG_TM_SLOTS;
+        while (__hip_atomic_load(&tgen[ts], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        add(ts);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t old = 0;
+        if (lane == 0u) old = __hip_atomic_fetch_add(&tarr[ts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        if (old == 3u) {                                             // wave-uniform: the last of the tile's four waves
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t first = range.x + bi * LG_Q;
+            const unsigned long long v = tacc[ts][lane];
+            tacc[ts][lane] = 0ull;
+            if (first + lane < range.y) {
+                const uint32_t id = (uint32_t)entries[first + lane] & gid_mask;
+                const uint32_t sl = lg_slot_of(tinfo[id], tx, ty);
+                if (sl < slot_cap) slots[sl] = v;                    // exactly one store per instance of the view: no atomics, no clear
+            }
+            if (lane == 0u) tarr[ts] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0u) __hip_atomic_store(&tgen[ts], want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     // the walk exists twice: tiles of one segment (every tile of the uniform benchmark scene) run the LONG = false copy,
     // which carries neither the segment accumulators nor the boundary test
     auto walk = [&](auto long_tag) {
@@ -218,7 +266,10 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 ck[(size_t)seg * 256] = make_float4(T, Cs0, Cs1, Cs2);
                 seg++; Cs0 = Cs1 = Cs2 = 0.0f;
             }
-            if (~donem == 0ull) break;       // every pixel of this wave is saturated or outside
+            if (~donem == 0ull) {            // every pixel of this wave is saturated or outside
+                if (MERGE) for (uint32_t b = (base - range.x) / LG_Q; b * LG_Q < range.y - range.x; b++) tile_leave(b, [](uint32_t) {});
+                break;
+            }
             const uint32_t idx = base + lane;
             bool hit = false;
             float4 r0, r1, r2;
@@ -229,7 +280,10 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 hit = lg_block_hit(r0, r1, r2, lg_reach(r0, r1, r2), bx0, by0);
             }
             const uint64_t mask = __ballot(hit);
-            if (mask == 0) continue;
+            if (mask == 0) {
+                if (MERGE) tile_leave((base - range.x) / LG_Q, [](uint32_t) {});
+                continue;
+            }
             if (hit) {
                 const uint32_t pos = prefix_popc(mask);
                 // the queue copy carries the entry's contributor index (1-based position in the tile's list) where the record has
@@ -238,7 +292,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                 // scalar ops, an add and a v_mov per hit)
                 r2.y = __uint_as_float(idx - range.x + 1u);
                 // per-hit weights: the entry's pre-sort slot rides where the box half-extent hy was (read by nothing after the block test)
-                if (FSCORE) r2.z = __uint_as_float(lg_slot_of(tinfo[__float_as_uint(r2.w) & LG_ID_MASK], tx, ty));
+                if (FSCORE && !MERGE) r2.z = __uint_as_float(lg_slot_of(tinfo[__float_as_uint(r2.w) & LG_ID_MASK], tx, ty));
                 q0[wave][pos] = r0; q1[wave][pos] = r1; q2[wave][pos] = r2;
             }
             __builtin_amdgcn_wave_barrier();
@@ -278,8 +332,16 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
                         const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
                         atomicAdd(&count[id], mycnt);
                     }
+                } else if (MERGE) {
+                    // {count : 16 | Q8.40 : 48} of this wave's 8 x 8 block into the tile's accumulator of the entry (its position in the batch)
+                    tile_leave((base - range.x) / LG_Q, [&](uint32_t ts) {
+                        if (owned < nhit && mycnt > 0) {
+                            const uint32_t src = __float_as_uint(q2[wave][owned].y) - 1u - (base - range.x);
+                            atomicAdd(&tacc[ts][src], ((unsigned long long)(uint32_t)mycnt << LG_SLOT_COUNT_SHIFT) + myfix);
+                        }
+                    });
                 } else if (owned < nhit && mycnt > 0) {
-                    // {count : 16 | Q8.40 : 48} of this wave's 8 x 8 block, into the (tile, Gaussian) instance's slot
+                    // count forwards that also return the image: one atomic per (wave, entry) into the (tile, Gaussian) instance's slot
                     const uint32_t slot = __float_as_uint(q2[wave][owned].z);
                     if (slot < slot_cap) atomicAdd(&slots[slot], ((unsigned long long)(uint32_t)mycnt << LG_SLOT_COUNT_SHIFT) + myfix);
                 }
@@ -849,18 +911,20 @@ lg_score_kernel(int N, const int32_t* __restrict__ count, const float* __restric
 }
 
 // per-view count and score of the ALPHA / ALPHA_T policies: every Gaussian sums the {count : 16 | Q8.40 : 48} words of its own instances
-// (consecutive pre-sort slots, tinfo.w .. + touched) -- integer adds, any order -- and rounds the Q24.40 total to fp32 ONCE (nearest even),
+// (consecutive pre-sort slots, offsets - touched .. offsets) -- integer adds, any order -- and rounds the Q24.40 total to fp32 ONCE (nearest even),
 // times 2^-40 (exact).  A lane walks up to LG_SLOT_SOLO slots itself; Gaussians with more (screen-filling splats) are summed by the whole wave.
 #define LG_SLOT_SOLO 16u
 __global__ void __launch_bounds__(256)
-lg_score_slots(int N, const uint32_t* __restrict__ touched, const uint4* __restrict__ tinfo, const unsigned long long* __restrict__ slots,
-               uint32_t slot_cap, int32_t* __restrict__ count, float* __restrict__ score, int32_t* __restrict__ count_sum)
+lg_score_slots(int N, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ offsets, const unsigned long long* __restrict__ slots,
+               uint32_t slot_cap, int32_t* __restrict__ count, float* __restrict__ score, int32_t* __restrict__ count_sum,
+               const uint32_t* __restrict__ counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t n = 0, base = 0;
-    if (i < N) { n = touched[i]; if (n) base = tinfo[i].w; }
-    if (base >= slot_cap || n > slot_cap - base) n = 0;           // (a view that outgrew its capacity is void anyway)
+    if (i < N) { n = touched[i]; base = offsets[i] - n; }          // offsets = inclusive scan of touched (lg_duplicate): the slot base without the 16-byte record
+    // a view that outgrew its capacity (or whose sort gave up) is void: its slots were never written -- it contributes zeros
+    if (counters[0] != 0u || base >= slot_cap || n > slot_cap - base) n = 0;
     uint64_t fix = 0; uint32_t cnt = 0;
     if (n <= LG_SLOT_SOLO)
         for (uint32_t k = 0; k < n; k++) { const uint64_t w = slots[base + k]; cnt += (uint32_t)(w >> LG_SLOT_COUNT_SHIFT); fix += w & ((1ull << LG_SLOT_COUNT_SHIFT) - 1ull); }
