@@ -182,11 +182,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
     // Significance-only pass with per-hit weights (MERGE): the four waves of a tile add their per-entry {count | weight} words into a ring of
     // LG_TM_SLOTS batch accumulators in LDS; whichever wave is the LAST to pass a batch writes the batch's 64 words to the instances' slots
     // with plain stores -- one store per (tile, Gaussian) instance, zeros included, so the slots need neither atomics nor a clear.
-#ifdef LG_MERGE_INT
-    constexpr bool MERGE = COUNT && !COLOR;               // experiment: the integer-weight significance pass merges per tile too
-#else
     constexpr bool MERGE = FSCORE != 0 && !COLOR;
-#endif
     __shared__ unsigned long long tacc[MERGE ? LG_TM_SLOTS : 1][MERGE ? LG_Q : 1];
     __shared__ uint32_t tarr[MERGE ? LG_TM_SLOTS : 1];      // waves that have passed the batch in the slot
     __shared__ uint32_t tgen[MERGE ? LG_TM_SLOTS : 1];      // flushes the slot has seen: batch b may use slot b % LG_TM_SLOTS once tgen == b / LG_TM_SLOTS
@@ -248,12 +244,8 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             tacc[ts][lane] = 0ull;
             if (first + lane < range.y) {
                 const uint32_t id = (uint32_t)entries[first + lane] & gid_mask;
-                if (FSCORE) {
-                    const uint32_t sl = lg_slot_of(tinfo[id], tx, ty);
-                    if (sl < slot_cap) slots[sl] = v;                // exactly one store per instance of the view: no atomics, no clear
-                } else if (v != 0ull) {
-                    atomicAdd(&count[id], (int)(uint32_t)v);         // integer weights: one atomic per (tile, entry) instead of one per (wave, entry)
-                }
+                const uint32_t sl = lg_slot_of(tinfo[id], tx, ty);
+                if (sl < slot_cap) slots[sl] = v;                    // exactly one store per instance of the view: no atomics, no clear
             }
             if (lane == 0u) tarr[ts] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -335,14 +327,7 @@ lg_blend_fwd(int W, int H, int gx, int ntiles, int ntiles_pad, const uint2* __re
             }
             if (COUNT) {
                 // lane j owns compacted entry j: one atomic per (wave, Gaussian), issued 64-wide (their cost: EXPERIMENTS.md, "significance pass")
-                if (!FSCORE && MERGE) {
-                    tile_leave((base - range.x) / LG_Q, [&](uint32_t ts) {
-                        if (lane < nhit && mycnt > 0) {
-                            const uint32_t src = __float_as_uint(q2[wave][lane].y) - 1u - (base - range.x);
-                            atomicAdd(&tacc[ts][src], (unsigned long long)(uint32_t)mycnt);
-                        }
-                    });
-                } else if (!FSCORE) {
+                if (!FSCORE) {
                     if (lane < nhit && mycnt > 0) {
                         const uint32_t id = __float_as_uint(q2[wave][lane].w) & LG_ID_MASK;
                         atomicAdd(&count[id], mycnt);
